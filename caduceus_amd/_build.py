@@ -1,0 +1,50 @@
+"""Build libcaduceus_hip.so (hipcc, gfx950) in-tree.  `python -m caduceus_amd._build` or __graft_entry__.build()."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcaduceus_hip.so")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = True) -> str:
+    """Cross-compiles every kernel for gfx950 (works without a GPU).  Objects are built in parallel."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "caduceus_hip.h")]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+    procs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        procs.append((src, obj, subprocess.Popen([hipcc, *flags, "-c", src, "-o", obj], stdout=subprocess.PIPE,
+                                                 stderr=subprocess.STDOUT)))
+    objs = []
+    for src, obj, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{out.decode()}")
+        if verbose and out.strip():
+            print(out.decode())
+        objs.append(obj)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv))

@@ -1,0 +1,199 @@
+"""ctypes binding of the C-ABI in include/caduceus_hip.h (libcaduceus_hip.so).
+
+The product path has NO fallback: if the HIP library has not been built, or a tensor is not on the GPU, the ops raise.
+`use_library_for_testing()` exists only so that the test-suite can inject the host-emulator build of the *same kernel
+sources* (tests/emu) on a machine without a GPU; nothing in this package calls it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcaduceus_hip.so")
+
+CAD_F32, CAD_BF16 = 0, 1
+PROF_KINDS = ("scan_fwd", "scan_bwd", "conv_fwd", "conv_bwd", "add_norm_fwd", "add_norm_bwd", "embed", "lm_head")
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i = C.c_int
+_f = C.c_float
+
+
+class EmbedArgs(C.Structure):
+    _fields_ = [("ids", _p), ("comp", _p), ("weight", _p), ("out", _p), ("B", _i64), ("L", _i64), ("D", _i), ("V", _i),
+                ("n_strands", _i), ("w_dtype", _i), ("out_dtype", _i)]
+
+
+class EmbedBwdArgs(C.Structure):
+    _fields_ = [("ids", _p), ("comp", _p), ("dout", _p), ("dweight", _p), ("B", _i64), ("L", _i64), ("D", _i),
+                ("V", _i), ("n_strands", _i), ("dout_dtype", _i)]
+
+
+class AddNormArgs(C.Structure):
+    _fields_ = [("x", _p), ("residual_in", _p), ("weight", _p), ("bias", _p), ("y", _p), ("residual_out", _p),
+                ("rstd", _p), ("mean", _p), ("rows_per_strand", _i64), ("n_strands", _i), ("D", _i), ("eps", _f),
+                ("is_rms", _i), ("swap_flip", _i), ("x_dtype", _i), ("y_dtype", _i)]
+
+
+class AddNormBwdArgs(C.Structure):
+    _fields_ = [("dy", _p), ("dres_out", _p), ("sum_saved", _p), ("rstd", _p), ("mean", _p), ("weight", _p),
+                ("dx", _p), ("dres_in", _p), ("dweight", _p), ("dbias", _p), ("rows_per_strand", _i64),
+                ("n_strands", _i), ("D", _i), ("is_rms", _i), ("swap_flip", _i), ("x_dtype", _i), ("y_dtype", _i)]
+
+
+class Conv1dArgs(C.Structure):
+    _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("out", _p), ("SB", _i64), ("L", _i64), ("split", _i64),
+                ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
+
+
+class Conv1dBwdArgs(C.Structure):
+    _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("dout", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
+                ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i),
+                ("dtype", _i)]
+
+
+class ScanArgs(C.Structure):
+    _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
+                ("delta_bias", _p), ("out", _p), ("chunk_state", _p), ("SB", _i64), ("L", _i64), ("split", _i64),
+                ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
+
+
+class ScanBwdArgs(C.Structure):
+    _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
+                ("delta_bias", _p), ("dout", _p), ("chunk_state", _p), ("du", _p), ("ddelta", _p), ("dz", _p),
+                ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
+                ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
+
+
+class LmHeadArgs(C.Structure):
+    _fields_ = [("hidden", _p), ("weight", _p), ("comp", _p), ("labels", _p), ("logits", _p), ("loss_sum", _p),
+                ("count", _p), ("rows", _i64), ("D", _i), ("V", _i), ("n_strands", _i), ("ignore_index", _i64),
+                ("dtype", _i)]
+
+
+# every exported symbol of include/caduceus_hip.h: name -> (restype, argtypes)
+SYMBOLS = {
+    "cad_version": (C.c_char_p, []),
+    "cad_status_string": (C.c_char_p, [_i]),
+    "cad_is_device_build": (_i, []),
+    "cad_embed_fwd": (_i, [C.POINTER(EmbedArgs), _p]),
+    "cad_embed_bwd": (_i, [C.POINTER(EmbedBwdArgs), _p]),
+    "cad_add_norm_fwd": (_i, [C.POINTER(AddNormArgs), _p]),
+    "cad_add_norm_bwd": (_i, [C.POINTER(AddNormBwdArgs), _p]),
+    "cad_conv1d_fwd": (_i, [C.POINTER(Conv1dArgs), _p]),
+    "cad_conv1d_bwd": (_i, [C.POINTER(Conv1dBwdArgs), _p]),
+    "cad_scan_fwd": (_i, [C.POINTER(ScanArgs), _p]),
+    "cad_scan_chunk_len": (_i64, []),
+    "cad_scan_state_floats": (_i64, [_i, _i64, _i64, _i]),
+    "cad_scan_bwd": (_i, [C.POINTER(ScanBwdArgs), _p]),
+    "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
+    "cad_prof_enable": (_i, [_i]),
+    "cad_prof_reset": (_i, []),
+    "cad_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+_lock = threading.Lock()
+_lib = None
+_is_device = None
+
+
+def _bind(path: str):
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def get_lib():
+    """The kernel library; raises loudly if it has not been built (no CPU fallback exists)."""
+    global _lib, _is_device
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} not found: the HIP kernels are not built. Run `python -m caduceus_amd._build` "
+                        "(needs hipcc; cross-compiles gfx950 without a GPU). caduceus_amd has no CPU fallback.")
+                _lib = _bind(LIB_PATH)
+                _is_device = bool(_lib.cad_is_device_build())
+    return _lib
+
+
+def is_device_build() -> bool:
+    get_lib()
+    return bool(_is_device)
+
+
+def use_library_for_testing(path: str | None):
+    """TEST HOOK: load an alternative build of the same C-ABI (the host emulator in tests/emu), or reset with None."""
+    global _lib, _is_device
+    with _lock:
+        if path is None:
+            _lib, _is_device = None, None
+        else:
+            _lib = _bind(path)
+            _is_device = bool(_lib.cad_is_device_build())
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {get_lib().cad_status_string(status).decode()} (status {status})")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return CAD_F32
+    if dt == torch.bfloat16:
+        return CAD_BF16
+    raise TypeError(f"caduceus_amd kernels support float32 and bfloat16 activations, got {dt}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_and_check(*tensors):
+    """Validates device placement against the loaded library flavour and returns the launch stream handle."""
+    dev_build = is_device_build()
+    ref = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev_build and not t.is_cuda:
+            raise RuntimeError("caduceus_amd: tensors must live on the GPU (no CPU fallback); got a CPU tensor")
+        if not dev_build and t.is_cuda:
+            raise RuntimeError("caduceus_amd: host-emulator library loaded but a GPU tensor was passed")
+        if ref is None:
+            ref = t
+        elif t.device != ref.device:
+            raise RuntimeError("caduceus_amd: all tensors of one op must be on the same device")
+        if not t.is_contiguous():
+            raise RuntimeError("caduceus_amd: kernel arguments must be contiguous")
+    if dev_build:
+        return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+    return None
+
+
+def prof_enable(on: bool):
+    check(get_lib().cad_prof_enable(int(on)), "cad_prof_enable")
+
+
+def prof_reset():
+    check(get_lib().cad_prof_reset(), "cad_prof_reset")
+
+
+def prof_read():
+    """{kind: (total_ms, launches)} for every timed kernel kind (synchronises the recorded events)."""
+    out = {}
+    for k, name in enumerate(PROF_KINDS):
+        ms, n = C.c_double(0), _i64(0)
+        check(get_lib().cad_prof_read(k, C.byref(ms), C.byref(n)), "cad_prof_read")
+        out[name] = (ms.value, n.value)
+    return out

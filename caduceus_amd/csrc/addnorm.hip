@@ -1,0 +1,198 @@
+// Fused residual-add + RMSNorm/LayerNorm over both RCPS strands, with the reference's fused-path strand swap
+// expressed as an output index map (include/caduceus_hip.h, cad_add_norm_*).
+//
+// One wave64 per token row; lane handles channels c = lane + 64*k.  HBM-bound elementwise kernel: every input
+// byte is read once and every output byte written once; statistics stay in registers (wave xor-reduction).
+#include "cad_common.h"
+
+namespace {
+
+#define AN_KMAX 16  // D <= 64 * AN_KMAX = 1024
+#define AN_WAVES 4  // rows per block-iteration
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_kernel(cad_add_norm_args a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t R = a.rows_per_strand;
+    const int64_t nrows = R * a.n_strands;
+    const int D = a.D;
+    const int kiter = (D + 63) >> 6;
+    const TX* x = (const TX*)a.x;
+    TY* y = (TY*)a.y;
+    const float invD = 1.0f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * AN_WAVES + wave; row < nrows; row += (int64_t)gridDim.x * AN_WAVES) {
+        const int s = (int)(row / R);
+        const int64_t r = row - (int64_t)s * R;
+        const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
+        float v[AN_KMAX];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < AN_KMAX; ++k) {
+            v[k] = 0.f;
+            const int c = lane + 64 * k;
+            if (k < kiter && c < D) {
+                float t = to_f32(x[row * D + c]);
+                if (a.residual_in) t += a.residual_in[row * D + c];
+                v[k] = t;
+                s1 += t;
+                s2 += t * t;
+            }
+        }
+        float mean = 0.f, rstd;
+        if (a.is_rms) {
+            s2 = wave_sum(s2);
+            rstd = cad_rsqrt(s2 * invD + a.eps);
+        } else {
+            s1 = wave_sum(s1);
+            mean = s1 * invD;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < AN_KMAX; ++k) {
+                const int c = lane + 64 * k;
+                if (k < kiter && c < D) {
+                    const float d = v[k] - mean;
+                    q += d * d;
+                }
+            }
+            q = wave_sum(q);
+            rstd = cad_rsqrt(q * invD + a.eps);
+        }
+        if (lane == 0) {
+            a.rstd[row] = rstd;
+            if (a.mean) a.mean[row] = mean;
+        }
+#pragma unroll
+        for (int k = 0; k < AN_KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (k < kiter && c < D) {
+                const int oc = a.swap_flip ? (D - 1 - c) : c;
+                float o = (v[k] - mean) * rstd * a.weight[oc];
+                if (a.bias) o += a.bias[oc];
+                y[orow * D + oc] = from_f32<TY>(o);
+                if (a.residual_out) a.residual_out[orow * D + oc] = v[k];
+            }
+        }
+    }
+}
+
+// Backward: rows are indexed in the INPUT index space; dy / dres_out / sum_saved are read through the map.
+#define ANB_ROWS_PER_WAVE 8
+template <typename TX, typename TY>
+__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_kernel(cad_add_norm_bwd_args a) {
+    __shared__ float red[AN_WAVES][64 * AN_KMAX];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t R = a.rows_per_strand;
+    const int64_t nrows = R * a.n_strands;
+    const int D = a.D;
+    const int kiter = (D + 63) >> 6;
+    const TY* dy = (const TY*)a.dy;
+    TX* dx = (TX*)a.dx;
+    const float invD = 1.0f / (float)D;
+    float dw[AN_KMAX], db[AN_KMAX];
+#pragma unroll
+    for (int k = 0; k < AN_KMAX; ++k) dw[k] = db[k] = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * AN_WAVES + wave) * ANB_ROWS_PER_WAVE;
+    for (int i = 0; i < ANB_ROWS_PER_WAVE; ++i) {
+        const int64_t row = row0 + i;
+        if (row >= nrows) break;
+        const int s = (int)(row / R);
+        const int64_t r = row - (int64_t)s * R;
+        const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
+        const float rstd = a.rstd[row];
+        const float mean = (a.is_rms || !a.mean) ? 0.f : a.mean[row];
+        float g[AN_KMAX], xh[AN_KMAX];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int k = 0; k < AN_KMAX; ++k) {
+            g[k] = xh[k] = 0.f;
+            const int c = lane + 64 * k;
+            if (k < kiter && c < D) {
+                const int oc = a.swap_flip ? (D - 1 - c) : c;
+                const float dyv = to_f32(dy[orow * D + oc]);
+                xh[k] = (a.sum_saved[orow * D + oc] - mean) * rstd;
+                g[k] = dyv * a.weight[oc];
+                sg += g[k];
+                sgx += g[k] * xh[k];
+                dw[k] += dyv * xh[k];
+                db[k] += dyv;
+            }
+        }
+        sgx = wave_sum(sgx) * invD;
+        sg = a.is_rms ? 0.f : wave_sum(sg) * invD;
+#pragma unroll
+        for (int k = 0; k < AN_KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (k < kiter && c < D) {
+                const int oc = a.swap_flip ? (D - 1 - c) : c;
+                float d = rstd * (g[k] - sg - xh[k] * sgx);
+                if (a.dres_out) d += a.dres_out[orow * D + oc];
+                dx[row * D + c] = from_f32<TX>(d);
+                if (a.dres_in) a.dres_in[row * D + c] = d;
+            }
+        }
+    }
+    // block-level reduction of the weight/bias gradients (indexed by OUTPUT channel), then one atomic per column
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !a.dbias) break;
+#pragma unroll
+        for (int k = 0; k < AN_KMAX; ++k) red[wave][lane + 64 * k] = pass == 0 ? dw[k] : db[k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += blockDim.x) {
+            float t = 0.f;
+            for (int w = 0; w < AN_WAVES; ++w) t += red[w][c];
+            const int oc = a.swap_flip ? (D - 1 - c) : c;
+            if (t != 0.f) atomicAdd(pass == 0 ? &a.dweight[oc] : &a.dbias[oc], t);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->x && a->weight && a->y && a->rstd);
+    CAD_CHECK_ARG(a->rows_per_strand > 0 && a->D > 0 && (a->n_strands == 1 || a->n_strands == 2));
+    CAD_CHECK_ARG(a->is_rms || a->mean);
+    if (a->D > 64 * AN_KMAX) return CAD_ERR_UNSUPPORTED;
+    CadProfScope prof(4, stream);
+    const int64_t nrows = a->rows_per_strand * a->n_strands;
+    int64_t nb = (nrows + AN_WAVES - 1) / AN_WAVES;
+    if (nb > 8192) nb = 8192;
+    dim3 grid((unsigned)nb), block(64 * AN_WAVES);
+    if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_F32)
+        CAD_LAUNCH((add_norm_fwd_kernel<float, float>), grid, block, 0, stream, *a);
+    else if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_BF16)
+        CAD_LAUNCH((add_norm_fwd_kernel<float, bf16_t>), grid, block, 0, stream, *a);
+    else if (a->x_dtype == CAD_BF16 && a->y_dtype == CAD_BF16)
+        CAD_LAUNCH((add_norm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, stream, *a);
+    else
+        return CAD_ERR_UNSUPPORTED;
+    return cad_after_launch();
+}
+
+extern "C" int cad_add_norm_bwd(const cad_add_norm_bwd_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->dy && a->sum_saved && a->rstd && a->weight && a->dx && a->dweight);
+    CAD_CHECK_ARG(a->rows_per_strand > 0 && a->D > 0 && (a->n_strands == 1 || a->n_strands == 2));
+    if (a->D > 64 * AN_KMAX) return CAD_ERR_UNSUPPORTED;
+    CadProfScope prof(5, stream);
+    const int64_t nrows = a->rows_per_strand * a->n_strands;
+    const int64_t per_block = (int64_t)AN_WAVES * ANB_ROWS_PER_WAVE;
+    dim3 grid((unsigned)((nrows + per_block - 1) / per_block)), block(64 * AN_WAVES);
+    if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_F32)
+        CAD_LAUNCH((add_norm_bwd_kernel<float, float>), grid, block, 0, stream, *a);
+    else if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_BF16)
+        CAD_LAUNCH((add_norm_bwd_kernel<float, bf16_t>), grid, block, 0, stream, *a);
+    else if (a->x_dtype == CAD_BF16 && a->y_dtype == CAD_BF16)
+        CAD_LAUNCH((add_norm_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, stream, *a);
+    else
+        return CAD_ERR_UNSUPPORTED;
+    return cad_after_launch();
+}

@@ -1,0 +1,105 @@
+// Library identification, status strings and the opt-in HIP-event kernel timer behind cad_prof_*.
+#include <mutex>
+#include <vector>
+
+#include "cad_common.h"
+
+extern "C" const char* cad_version(void) {
+#ifdef CAD_EMU
+    return "caduceus_amd 0.1.0 (host emulator build - tests only)";
+#else
+    return "caduceus_amd 0.1.0 (hip gfx950)";
+#endif
+}
+
+extern "C" int cad_is_device_build(void) { return CAD_DEVICE_BUILD; }
+
+extern "C" const char* cad_status_string(int s) {
+    switch (s) {
+        case CAD_OK: return "ok";
+        case CAD_ERR_BAD_ARG: return "bad argument (null pointer, shape or alignment)";
+        case CAD_ERR_UNSUPPORTED: return "unsupported configuration (dtype / size outside the compiled range)";
+        case CAD_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown status";
+    }
+}
+
+int cad_after_launch() { return hipGetLastError() == hipSuccess ? CAD_OK : CAD_ERR_LAUNCH; }
+
+namespace {
+std::mutex g_mu;
+bool g_on = false;
+#ifndef CAD_EMU
+struct Rec {
+    int kind;
+    hipEvent_t a, b;
+};
+std::vector<Rec> g_recs;
+#else
+int64_t g_counts[CAD_PROF_KINDS];
+#endif
+}  // namespace
+
+CadProfScope::CadProfScope(int k, void* s) : kind(k), stream(s), slot(-1) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_on) return;
+#ifndef CAD_EMU
+    Rec r;
+    r.kind = k;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    hipEventRecord(r.a, (hipStream_t)s);
+    g_recs.push_back(r);
+    slot = (int)g_recs.size() - 1;
+#else
+    g_counts[k]++;
+#endif
+}
+
+CadProfScope::~CadProfScope() {
+#ifndef CAD_EMU
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (slot >= 0 && slot < (int)g_recs.size()) hipEventRecord(g_recs[slot].b, (hipStream_t)stream);
+#endif
+}
+
+extern "C" int cad_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return CAD_OK;
+}
+
+extern "C" int cad_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+#ifndef CAD_EMU
+    for (auto& r : g_recs) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+#else
+    for (int i = 0; i < CAD_PROF_KINDS; ++i) g_counts[i] = 0;
+#endif
+    return CAD_OK;
+}
+
+extern "C" int cad_prof_read(int kind, double* total_ms, int64_t* launches) {
+    if (kind < 0 || kind >= CAD_PROF_KINDS || !total_ms || !launches) return CAD_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    double t = 0;
+    int64_t n = 0;
+#ifndef CAD_EMU
+    for (auto& r : g_recs) {
+        if (r.kind != kind) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return CAD_ERR_LAUNCH;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return CAD_ERR_LAUNCH;
+        t += ms;
+        n++;
+    }
+#else
+    n = g_counts[kind];
+#endif
+    *total_ms = t;
+    *launches = n;
+    return CAD_OK;
+}

@@ -1,0 +1,139 @@
+// Shared device/host helpers for the Caduceus gfx950 kernels.
+//
+// The kernels are written for CDNA4 (wave64, LDS, HBM-coalesced channel-major streams).  The only portability
+// seam is CAD_EMU: the test-suite compiles these same sources with g++ against tests/emu/emu_runtime.h so that
+// kernel logic can be parity-checked against the oracle on a machine without a GPU.  There is no CUDA path.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/caduceus_hip.h"
+
+#ifdef CAD_EMU
+#include "emu_runtime.h"
+#define CAD_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), (shmem), [=]() { kern(__VA_ARGS__); })
+#define CAD_DEVICE_BUILD 0
+#else
+#include <hip/hip_runtime.h>
+#define CAD_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (shmem), (hipStream_t)(stream), __VA_ARGS__)
+#define CAD_DEVICE_BUILD 1
+#endif
+
+#define CAD_WAVE 64
+
+// dynamic LDS (16-byte aligned base; keep ALL of a kernel's LDS in this one region - guide G17)
+#ifdef CAD_EMU
+#define CAD_DYN_SMEM(T, name) T* name = (T*)emu::dyn_smem()
+#else
+#define CAD_DYN_SMEM(T, name)                                              \
+    extern __shared__ __attribute__((aligned(16))) char cad_smem_raw[];   \
+    T* name = (T*)cad_smem_raw
+#endif
+
+// ---- small numeric helpers ---------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((vector_size(8)));  // maps to v_pk_{mul,fma,add}_f32 on gfx950
+
+struct bf16_t {
+    uint16_t v;
+};
+
+__device__ __forceinline__ float cad_bits2f(uint32_t u) {
+    union {
+        uint32_t u;
+        float f;
+    } c;
+    c.u = u;
+    return c.f;
+}
+__device__ __forceinline__ uint32_t cad_f2bits(float f) {
+    union {
+        uint32_t u;
+        float f;
+    } c;
+    c.f = f;
+    return c.u;
+}
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return cad_bits2f((uint32_t)x.v << 16); }
+template <typename T>
+__device__ __forceinline__ T from_f32(float f);
+template <>
+__device__ __forceinline__ float from_f32<float>(float f) {
+    return f;
+}
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = cad_f2bits(f);
+    bf16_t r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) {
+        r.v = (uint16_t)((u >> 16) | 0x40);
+    } else {
+        u += 0x7fffu + ((u >> 16) & 1u);
+        r.v = (uint16_t)(u >> 16);
+    }
+    return r;
+}
+
+#define CAD_LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ float cad_exp2(float x) {
+#ifdef CAD_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);  // v_exp_f32
+#endif
+}
+__device__ __forceinline__ float cad_exp(float x) { return cad_exp2(x * CAD_LOG2E); }
+__device__ __forceinline__ float cad_log(float x) {
+#ifdef CAD_EMU
+    return logf(x);
+#else
+    return __builtin_amdgcn_logf(x) * 0.6931471805599453f;  // v_log_f32 (log2) * ln2
+#endif
+}
+__device__ __forceinline__ float cad_rcp(float x) {
+#ifdef CAD_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float cad_rsqrt(float x) {
+#ifdef CAD_EMU
+    return 1.0f / sqrtf(x);
+#else
+    return __builtin_amdgcn_rsqf(x);
+#endif
+}
+// softplus with the upstream threshold (x > 20 -> x); log1p(e) evaluated as log(w) * e / (w - 1), w = 1 + e,
+// which is accurate to ~1 ulp also for tiny e (plain log(1+e) loses all digits there).
+__device__ __forceinline__ float cad_softplus(float x) {
+    if (x > 20.0f) return x;
+    float e = cad_exp(x);
+    float w = 1.0f + e;
+    float d = w - 1.0f;
+    return (d == 0.0f) ? e : cad_log(w) * (e * cad_rcp(d));
+}
+__device__ __forceinline__ float cad_sigmoid(float x) { return cad_rcp(1.0f + cad_exp(-x)); }
+
+// ---- direction / index maps ----------------------------------------------------------------------------------
+// logical position p in [0, L) of a row <-> physical index along L
+__device__ __forceinline__ int64_t cad_phys(int64_t p, int64_t L, int rev) { return rev ? (L - 1 - p) : p; }
+
+// ---- host side -------------------------------------------------------------------------------------------------
+#define CAD_CHECK_ARG(cond)              \
+    do {                                 \
+        if (!(cond)) return CAD_ERR_BAD_ARG; \
+    } while (0)
+
+int cad_after_launch();  // hipGetLastError -> cad_status
+
+// RAII kernel timer (no-op unless cad_prof_enable(1)); see api.hip
+struct CadProfScope {
+    int kind;
+    void* stream;
+    int slot;
+    CadProfScope(int kind, void* stream);
+    ~CadProfScope();
+};

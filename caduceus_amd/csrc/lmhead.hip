@@ -1,0 +1,105 @@
+// RCPS LM head (16-way vocabulary) fused with fp32 logits and the masked cross-entropy partial sums
+// (include/caduceus_hip.h, cad_lm_head_fwd).  One wave64 per token; W (V x D fp32, <= 16 KB) is read through L1.
+#include "cad_common.h"
+
+namespace {
+
+#define LM_VMAX 16
+#define LM_WAVES 4
+
+template <typename T>
+__global__ __launch_bounds__(64 * LM_WAVES) void lm_head_fwd_kernel(cad_lm_head_args a) {
+    __shared__ float red[LM_WAVES][2];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int D = a.D, V = a.V;
+    const T* hid = (const T*)a.hidden;
+    float loss_part = 0.f, cnt_part = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * LM_WAVES + wave; row < a.rows; row += (int64_t)gridDim.x * LM_WAVES) {
+        float acc[LM_VMAX];
+#pragma unroll
+        for (int v = 0; v < LM_VMAX; ++v) acc[v] = 0.f;
+        for (int s = 0; s < a.n_strands; ++s) {
+            const T* h = hid + ((int64_t)s * a.rows + row) * D;
+            for (int c = lane; c < D; c += 64) {
+                const float hv = to_f32(h[c]);
+#pragma unroll
+                for (int v = 0; v < LM_VMAX; ++v) {
+                    if (v < V) {
+                        const int64_t wr = (s == 1) ? a.comp[v] : v;
+                        acc[v] += hv * a.weight[wr * D + c];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < LM_VMAX; ++v) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc[v] += __shfl_xor(acc[v], m);
+        }
+        if (lane == 0) {
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int v = 0; v < LM_VMAX; ++v) {
+                if (v < V) {
+                    a.logits[row * V + v] = acc[v];
+                    mx = acc[v] > mx ? acc[v] : mx;
+                }
+            }
+            if (a.labels) {
+                const int64_t lab = a.labels[row];
+                if (lab != a.ignore_index && lab >= 0 && lab < V) {
+                    float se = 0.f, pick = 0.f;
+#pragma unroll
+                    for (int v = 0; v < LM_VMAX; ++v) {
+                        if (v < V) {
+                            se += expf(acc[v] - mx);
+                            if (v == lab) pick = acc[v];
+                        }
+                    }
+                    loss_part += (logf(se) + mx) - pick;
+                    cnt_part += 1.f;
+                }
+            }
+        }
+    }
+    if (a.labels) {
+        if (lane == 0) {
+            red[wave][0] = loss_part;
+            red[wave][1] = cnt_part;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float l = 0.f, n = 0.f;
+            for (int w = 0; w < LM_WAVES; ++w) {
+                l += red[w][0];
+                n += red[w][1];
+            }
+            if (n > 0.f) {
+                atomicAdd(a.loss_sum, l);
+                atomicAdd(a.count, n);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->hidden && a->weight && a->logits);
+    CAD_CHECK_ARG(a->rows > 0 && a->D > 0 && a->V > 0);
+    CAD_CHECK_ARG(a->n_strands == 1 || (a->n_strands == 2 && a->comp));
+    CAD_CHECK_ARG(!a->labels || (a->loss_sum && a->count));
+    if (a->V > LM_VMAX) return CAD_ERR_UNSUPPORTED;
+    CadProfScope prof(7, stream);
+    int64_t nb = (a->rows + LM_WAVES - 1) / LM_WAVES;
+    if (nb > 4096) nb = 4096;
+    dim3 grid((unsigned)nb), block(64 * LM_WAVES);
+    if (a->dtype == CAD_F32)
+        CAD_LAUNCH((lm_head_fwd_kernel<float>), grid, block, 0, stream, *a);
+    else if (a->dtype == CAD_BF16)
+        CAD_LAUNCH((lm_head_fwd_kernel<bf16_t>), grid, block, 0, stream, *a);
+    else
+        return CAD_ERR_UNSUPPORTED;
+    return cad_after_launch();
+}

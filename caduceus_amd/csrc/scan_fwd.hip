@@ -1,0 +1,132 @@
+// Selective SSM scan, forward (include/caduceus_hip.h, cad_scan_fwd).  See scan_common.h for the decomposition.
+#include "scan_common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(64 * SC_W) void scan_fwd_kernel(cad_scan_args a) {
+    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t sb = blockIdx.y;
+    const int e_raw = blockIdx.x * SC_W + wave;
+    const bool act = e_raw < a.E;
+    const int e = act ? e_raw : a.E - 1;
+    const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
+    const int64_t L = a.L, SB = a.SB;
+    const int N = a.N, NP = (N + 1) >> 1;
+    const int64_t row_off = ((int64_t)e * SB + sb) * L;
+    const T* u_row = (const T*)a.u + row_off;
+    const T* d_row = (const T*)a.delta + row_off;
+    const T* z_row = a.z ? (const T*)a.z + row_off : nullptr;
+    T* o_row = (T*)a.out + row_off;
+    const T* Bm = (const T*)a.Bm;
+    const T* Cm = (const T*)a.Cm;
+    const bool vec_ok = ((L * sizeof(T)) % 16) == 0 &&
+                        (((uintptr_t)a.u | (uintptr_t)a.delta | (uintptr_t)a.z | (uintptr_t)a.out) % 16) == 0;
+    const float Dv = a.D ? a.D[e] : 0.f;
+    const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
+    const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
+
+    f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int64_t base = c * SC_CHUNK;
+        const int64_t p0 = base + (int64_t)lane * SC_S;
+        float du[SC_S], dt[SC_S], y[SC_S];
+        sc_load(u_row, p0, L, rev, vec_ok, du);
+        sc_load(d_row, p0, L, rev, vec_ok, dt);
+#pragma unroll
+        for (int i = 0; i < SC_S; ++i) {
+            dt[i] = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
+            y[i] = Dv * du[i];
+            du[i] *= dt[i];
+        }
+        if (a.chunk_state && act && lane < NP) {
+            float* st = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
+            st[0] = carry[0];
+            st[1] = carry[1];
+        }
+        sc_stage_bc(smem, smem + SC_TILE, Bm, Cm, 0, N, SB, sb, base, L, rev);
+        __syncthreads();
+        for (int np = 0; np < NP; ++np) {
+            const int buf = np & 1;
+            if (np + 1 < NP)
+                sc_stage_bc(smem + (buf ^ 1) * 2 * SC_TILE, smem + (buf ^ 1) * 2 * SC_TILE + SC_TILE, Bm, Cm,
+                            2 * (np + 1), N, SB, sb, base, L, rev);
+            const float* tB = smem + buf * 2 * SC_TILE + lane * SC_ROW;
+            const float* tC = tB + SC_TILE;
+            const int n0 = 2 * np;
+            const f32x2 A2 = f2(a.A[e * N + n0] * CAD_LOG2E, (n0 + 1 < N) ? a.A[e * N + n0 + 1] * CAD_LOG2E : 0.f);
+            // (i) serial scan over the lane's items
+            f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
+            f32x2 ha[SC_S], hh[SC_S];
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                const f32x2 av = exp2_2(f2(dt[i]) * A2);
+                const f32x2 bv = f2(du[i]) * ld2(tB + 2 * i);
+                acc_h = av * acc_h + bv;
+                acc_a = acc_a * av;
+                ha[i] = acc_a;
+                hh[i] = acc_h;
+            }
+            // (ii) inclusive Kogge-Stone scan of the affine maps across lanes
+            f32x2 PA = acc_a, PH = acc_h;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const f32x2 ua = shfl_up2(PA, d), uh = shfl_up2(PH, d);
+                if (lane >= d) {
+                    PH = PA * uh + PH;
+                    PA = PA * ua;
+                }
+            }
+            f32x2 ea = shfl_up2(PA, 1), eh = shfl_up2(PH, 1);
+            if (lane == 0) {
+                ea = f2(1.f);
+                eh = f2(0.f);
+            }
+            // (iii) carry in / out
+            const f32x2 hin = shfl2(carry, np);
+            const f32x2 h0 = ea * hin + eh;
+            const f32x2 newc = shfl2(PA * hin + PH, 63);
+            if (lane == np) carry = newc;
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                const f32x2 h = ha[i] * h0 + hh[i];
+                y[i] += dot2(ld2(tC + 2 * i), h);
+            }
+            __syncthreads();
+        }
+        if (z_row) {
+            float zz[SC_S];
+            sc_load(z_row, p0, L, rev, vec_ok, zz);
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) y[i] *= zz[i] * cad_sigmoid(zz[i]);
+        }
+        if (act) sc_store(o_row, p0, L, rev, vec_ok, y);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t cad_scan_chunk_len(void) { return SC_CHUNK; }
+
+extern "C" int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N) {
+    const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
+    return (int64_t)E * SB * nchunks * ((N + 1) / 2) * 2;
+}
+
+extern "C" int cad_scan_fwd(const cad_scan_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->u && a->delta && a->A && a->Bm && a->Cm && a->out);
+    CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
+    CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
+    CadProfScope prof(0, stream);
+    dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB), block(64 * SC_W);
+    const size_t shmem = (size_t)4 * SC_TILE * sizeof(float);
+    if (a->dtype == CAD_F32)
+        CAD_LAUNCH((scan_fwd_kernel<float>), grid, block, shmem, stream, *a);
+    else if (a->dtype == CAD_BF16)
+        CAD_LAUNCH((scan_fwd_kernel<bf16_t>), grid, block, shmem, stream, *a);
+    else
+        return CAD_ERR_UNSUPPORTED;
+    return cad_after_launch();
+}

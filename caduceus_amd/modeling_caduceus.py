@@ -1,0 +1,421 @@
+"""Caduceus model for Hugging Face, MI355X-native engine behind the reference's surface.
+
+Same public classes, constructor / forward signatures, module tree and state-dict keys as
+/root/reference/caduceus/modeling_caduceus.py, so `train.py`-style loops (`model(input_ids).logits`), the HF `AutoModel`
+path and reference checkpoints work unchanged; all arithmetic runs in the flip-free t-frame on the HIP kernels
+(caduceus_amd.engine / caduceus_amd.ops).  No dependency on mamba_ssm / causal_conv1d / triton.
+"""
+import math
+from functools import partial
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+from transformers import PreTrainedModel
+from transformers.modeling_outputs import BaseModelOutputWithNoAttention, MaskedLMOutput, SequenceClassifierOutput
+
+from . import engine, ops
+from .configuration_caduceus import CaduceusConfig
+from .mamba import Block, Mamba, RMSNorm, act_dtype_of, norm_params
+from .modeling_rcps import RCPSAddNormWrapper, RCPSEmbedding, RCPSLMHead, RCPSMambaBlock
+
+
+def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, rms_norm=False, residual_in_fp32=False,
+                 fused_add_norm=False, layer_idx=None, bidirectional=True, bidirectional_strategy="add",
+                 bidirectional_weight_tie=True, rcps=False, device=None, dtype=None):
+    """modeling_caduceus.py:33-84."""
+    if ssm_cfg is None:
+        ssm_cfg = {}
+    factory_kwargs = {"device": device, "dtype": dtype}
+    bidirectional_kwargs = {
+        "bidirectional": bidirectional,
+        "bidirectional_strategy": bidirectional_strategy,
+        "bidirectional_weight_tie": bidirectional_weight_tie,
+    }
+    mixer_cls = partial(BiMambaWrapper, layer_idx=layer_idx, **ssm_cfg, **bidirectional_kwargs, **factory_kwargs)
+    norm_cls = partial(nn.LayerNorm if not rms_norm else RMSNorm, eps=norm_epsilon, **factory_kwargs)
+    block_cls = RCPSMambaBlock if rcps else Block
+    block = block_cls(d_model, mixer_cls, norm_cls=norm_cls, fused_add_norm=fused_add_norm,
+                      residual_in_fp32=residual_in_fp32)
+    block.layer_idx = layer_idx
+    return block
+
+
+class BiMambaWrapper(nn.Module):
+    """modeling_caduceus.py:87-140: weight-tied forward + reverse Mamba; here one shared in_proj, two index-mapped
+    scans, one accumulated out_proj."""
+
+    def __init__(self, d_model: int, bidirectional: bool = True, bidirectional_strategy: Optional[str] = "add",
+                 bidirectional_weight_tie: bool = True, **mamba_kwargs):
+        super().__init__()
+        if bidirectional and bidirectional_strategy is None:
+            bidirectional_strategy = "add"
+        if bidirectional and bidirectional_strategy not in ["add", "ew_multiply"]:
+            raise NotImplementedError(f"`{bidirectional_strategy}` strategy for bi-directionality is not implemented!")
+        self.bidirectional = bidirectional
+        self.bidirectional_strategy = bidirectional_strategy
+        self.mamba_fwd = Mamba(d_model=d_model, **mamba_kwargs)
+        if bidirectional:
+            self.mamba_rev = Mamba(d_model=d_model, **mamba_kwargs)
+            if bidirectional_weight_tie:
+                self.mamba_rev.in_proj.weight = self.mamba_fwd.in_proj.weight
+                self.mamba_rev.in_proj.bias = self.mamba_fwd.in_proj.bias
+                self.mamba_rev.out_proj.weight = self.mamba_fwd.out_proj.weight
+                self.mamba_rev.out_proj.bias = self.mamba_fwd.out_proj.bias
+        else:
+            self.mamba_rev = None
+
+    def forward_tframe(self, hn: torch.Tensor, strand_swap: bool) -> torch.Tensor:
+        return engine.bimamba_tframe(hn, self.mamba_fwd, self.mamba_rev if self.bidirectional else None,
+                                     self.bidirectional_strategy, strand_swap)
+
+    def forward(self, hidden_states, inference_params=None):
+        """hidden_states: (B, L, D) -> same shape."""
+        if inference_params is not None:
+            raise NotImplementedError("step-wise inference cache is outside the pre-training hot path")
+        act = act_dtype_of(hidden_states)
+        return self.forward_tframe(hidden_states.to(act).unsqueeze(0), strand_swap=False)[0]
+
+    def allocate_inference_cache(self, *args, **kwargs):
+        raise NotImplementedError("step-wise inference cache is outside the pre-training hot path")
+
+
+class CaduceusEmbeddings(nn.Module):
+    """modeling_caduceus.py:143-163."""
+
+    def __init__(self, config: CaduceusConfig, device=None, dtype=None):
+        super().__init__()
+        factory_kwargs = {"device": device, "dtype": dtype}
+        if config.rcps:
+            self.word_embeddings = RCPSEmbedding(config.vocab_size, config.d_model, config.complement_map,
+                                                 **factory_kwargs)
+        else:
+            self.word_embeddings = nn.Embedding(config.vocab_size, config.d_model, **factory_kwargs)
+
+    def forward_tframe(self, input_ids, out_dtype=torch.float32):
+        we = self.word_embeddings
+        if isinstance(we, RCPSEmbedding):
+            return we.forward_tframe(input_ids, out_dtype)
+        return ops.embed(input_ids, we.weight, None, 1, out_dtype)
+
+    def forward(self, input_ids):
+        return engine.from_tframe(self.forward_tframe(input_ids, self.word_embeddings.weight.dtype))
+
+
+class CaduceusMixerModel(nn.Module):
+    """modeling_caduceus.py:166-276."""
+
+    def __init__(self, config: CaduceusConfig, device=None, dtype=None) -> None:
+        super().__init__()
+        factory_kwargs = {"device": device, "dtype": dtype}
+        self.fused_add_norm = config.fused_add_norm
+        self.rcps = config.rcps
+        self.residual_in_fp32 = config.residual_in_fp32
+        self.embeddings = CaduceusEmbeddings(config, **factory_kwargs)
+        self.layers = nn.ModuleList([
+            create_block(config.d_model, ssm_cfg=config.ssm_cfg, norm_epsilon=config.norm_epsilon,
+                         rms_norm=config.rms_norm, residual_in_fp32=config.residual_in_fp32,
+                         fused_add_norm=config.fused_add_norm, layer_idx=i, bidirectional=config.bidirectional,
+                         bidirectional_strategy=config.bidirectional_strategy,
+                         bidirectional_weight_tie=config.bidirectional_weight_tie, rcps=config.rcps, **factory_kwargs)
+            for i in range(config.n_layer)
+        ])
+        norm_f = (nn.LayerNorm if not config.rms_norm else RMSNorm)(config.d_model, eps=config.norm_epsilon,
+                                                                    **factory_kwargs)
+        self.norm_f = norm_f if (config.fused_add_norm or not config.rcps) else RCPSAddNormWrapper(norm_f)
+
+    def forward_tframe(self, input_ids, inputs_embeds=None, collect: Optional[list] = None) -> torch.Tensor:
+        """Returns the final normed hidden state in the t-frame (S, B, L, D) in the compute dtype."""
+        if inputs_embeds is not None:
+            act = act_dtype_of(inputs_embeds)
+            hidden = engine.to_tframe(inputs_embeds, self.rcps)
+            if hidden.dtype not in (torch.float32, act):
+                hidden = hidden.to(act)
+        else:
+            w = self.embeddings.word_embeddings.weight
+            act = act_dtype_of(w)
+            hidden = self.embeddings.forward_tframe(input_ids, torch.float32 if w.dtype == torch.float32 else act)
+        residual = None
+        for layer in self.layers:
+            if collect is not None:
+                collect.append(hidden)
+            hidden, residual = layer.forward_tframe(hidden, residual, act)
+        nf = self.norm_f.submodule if isinstance(self.norm_f, RCPSAddNormWrapper) else self.norm_f
+        w, b, eps, is_rms = norm_params(nf)
+        # final norm never swaps strands (modeling_caduceus.py:234-262)
+        hidden, _ = ops.add_norm(hidden, residual, w, b, eps, is_rms, False, act)
+        if collect is not None and self.fused_add_norm:  # reference quirk: appended only in the fused branch (:274-275)
+            collect.append(hidden)
+        return hidden
+
+    def forward(self, input_ids, inputs_embeds=None, output_hidden_states=False):
+        """Mixer forward: returns (hidden_states (B, L, 2D | D), all_hidden_states)."""
+        collect = [] if output_hidden_states else None
+        hidden = self.forward_tframe(input_ids, inputs_embeds, collect)
+        all_hidden_states = [engine.from_tframe(h) for h in collect] if collect is not None else []
+        return engine.from_tframe(hidden), all_hidden_states
+
+
+def _first(outputs):
+    """Backbone output when `return_dict=False` may be a bare tensor."""
+    return outputs if isinstance(outputs, torch.Tensor) else outputs[0]
+
+
+def cross_entropy(logits, y, ignore_index=-100):
+    """modeling_caduceus.py:279-283."""
+    logits = logits.view(-1, logits.shape[-1])
+    y = y.view(-1)
+    return F.cross_entropy(logits, y, ignore_index=ignore_index)
+
+
+def weighted_cross_entropy(logits, y, loss_weights, ignore_index=-100):
+    """modeling_caduceus.py:286-294."""
+    logits = logits.view(-1, logits.shape[-1])
+    y = y.view(-1)
+    ce = F.cross_entropy(logits, y, ignore_index=ignore_index, reduction="none")
+    loss_weights = loss_weights.view(-1)
+    loss_weights[y == ignore_index] = 0.0
+    return (ce * (loss_weights / loss_weights.sum())).sum()
+
+
+class CaduceusPreTrainedModel(PreTrainedModel):
+    """modeling_caduceus.py:297-341."""
+    config_class = CaduceusConfig
+    base_model_prefix = "caduceus"
+    supports_gradient_checkpointing = False
+    _no_split_modules = ["BiMambaWrapper"]
+
+    def _init_weights(self, module, initializer_range=0.02, **kwargs):
+        n_layer = self.config.n_layer
+        initialized_cfg = self.config.initializer_cfg if self.config.initializer_cfg is not None else {}
+        rescale_prenorm_residual = initialized_cfg.get("rescale_prenorm_residual", True)
+        initializer_range = initialized_cfg.get("initializer_range", initializer_range)
+        n_residuals_per_layer = initialized_cfg.get("n_residuals_per_layer", 1)
+        if isinstance(module, nn.Linear):
+            if module.bias is not None:
+                if not getattr(module.bias, "_no_reinit", False):
+                    nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.Embedding):
+            nn.init.normal_(module.weight, std=initializer_range)
+        if rescale_prenorm_residual:
+            for name, p in module.named_parameters():
+                if name in ["out_proj.weight", "fc2.weight"]:
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                    with torch.no_grad():
+                        p /= math.sqrt(n_residuals_per_layer * n_layer)
+
+    @property
+    def _return_dict_default(self):
+        rd = getattr(self.config, "return_dict", None)
+        return True if rd is None else rd
+
+
+class Caduceus(CaduceusPreTrainedModel):
+    """modeling_caduceus.py:344-389."""
+
+    def __init__(self, config: CaduceusConfig, device=None, dtype=None, **kwargs):
+        super().__init__(config)
+        if config.rcps:
+            assert config.complement_map is not None, "Complement map must be provided for RCPS."
+        if config.vocab_size % config.pad_vocab_size_multiple != 0:
+            config.vocab_size += config.pad_vocab_size_multiple - (config.vocab_size % config.pad_vocab_size_multiple)
+        if config.complement_map is not None and config.vocab_size > len(config.complement_map):
+            for i in range(len(config.complement_map), config.vocab_size):
+                config.complement_map[i] = i
+        self.config = config
+        factory_kwargs = {"device": device, "dtype": dtype}
+        self.backbone = CaduceusMixerModel(config, **factory_kwargs, **kwargs)
+
+    def forward(self, input_ids: torch.LongTensor = None, inputs_embeds: Optional[torch.FloatTensor] = None,
+                output_hidden_states: Optional[bool] = None, return_dict: Optional[bool] = None,
+                ) -> Union[torch.Tensor, Tuple, BaseModelOutputWithNoAttention]:
+        output_hidden_states = (output_hidden_states if output_hidden_states is not None
+                                else self.config.output_hidden_states)
+        return_dict = return_dict if return_dict is not None else self._return_dict_default
+        hidden_states, all_hidden_states = self.backbone(input_ids, inputs_embeds=inputs_embeds,
+                                                         output_hidden_states=output_hidden_states)
+        if return_dict:
+            return BaseModelOutputWithNoAttention(last_hidden_state=hidden_states,
+                                                  hidden_states=all_hidden_states if output_hidden_states else None)
+        elif output_hidden_states:
+            return hidden_states, all_hidden_states
+        else:
+            return hidden_states
+
+
+class CaduceusForMaskedLM(CaduceusPreTrainedModel):
+    """modeling_caduceus.py:392-492."""
+
+    def __init__(self, config: CaduceusConfig, device=None, dtype=None, **kwargs):
+        super().__init__(config, **kwargs)
+        factory_kwargs = {"device": device, "dtype": dtype}
+        self.caduceus = Caduceus(config, **factory_kwargs, **kwargs)
+        if config.rcps:
+            self.lm_head = RCPSLMHead(complement_map=self.config.complement_map, vocab_size=self.config.vocab_size,
+                                      true_dim=config.d_model, dtype=dtype)
+            self._tied_weights_keys = {
+                "lm_head.lm_head.weight": "caduceus.backbone.embeddings.word_embeddings.embedding.weight"}
+        else:
+            self.lm_head = nn.Linear(config.d_model, self.config.vocab_size, bias=False, **factory_kwargs)
+            self._tied_weights_keys = {"lm_head.weight": "caduceus.backbone.embeddings.word_embeddings.weight"}
+        self.post_init()
+
+    def get_input_embeddings(self):
+        return self.caduceus.backbone.embeddings.word_embeddings
+
+    def set_input_embeddings(self, value):
+        if self.config.rcps:
+            raise NotImplementedError("Setting input embeddings for RCPS LM is not supported.")
+        self.caduceus.backbone.embeddings.word_embeddings = value
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_output_embeddings(self, new_embeddings):
+        if self.config.rcps:
+            raise NotImplementedError("Setting output embeddings for RCPS LM is not supported.")
+        self.lm_head = new_embeddings
+
+    def tie_weights(self, *args, **kwargs):
+        """Tie weights, accounting for RCPS (modeling_caduceus.py:434-439).  Accepts (and ignores) the keyword
+        arguments newer transformers releases pass."""
+        if not getattr(self.config, "tie_word_embeddings", True):
+            return
+        if self.config.rcps:
+            self.lm_head.set_weight(self.get_input_embeddings().weight)
+        else:
+            self.lm_head.weight = self.get_input_embeddings().weight
+
+    def get_decoder(self):
+        return self.caduceus
+
+    def set_decoder(self, decoder):
+        self.caduceus = decoder
+
+    def forward(self, input_ids: torch.LongTensor = None, inputs_embeds: Optional[torch.FloatTensor] = None,
+                labels: Optional[torch.LongTensor] = None, loss_weights: Optional[torch.FloatTensor] = None,
+                output_hidden_states: Optional[bool] = None, return_dict: Optional[bool] = None,
+                ) -> Union[Tuple, MaskedLMOutput]:
+        output_hidden_states = (output_hidden_states if output_hidden_states is not None
+                                else self.config.output_hidden_states)
+        return_dict = return_dict if return_dict is not None else self._return_dict_default
+        backbone = self.caduceus.backbone
+        collect = [] if output_hidden_states else None
+        hidden_t = backbone.forward_tframe(input_ids, inputs_embeds, collect)  # (S, B, L, D), never leaves the t-frame
+        ignore_index = getattr(self.config, "pad_token_id", None)
+        ignore_index = -100 if ignore_index is None else ignore_index
+        fused_loss = labels is not None and loss_weights is None
+        if self.config.rcps:
+            logits, loss = self.lm_head.forward_tframe(hidden_t, labels if fused_loss else None, ignore_index)
+        else:
+            w = self.lm_head.weight
+            if w.shape[0] <= 16 and getattr(self.lm_head, "bias", None) is None:
+                logits, loss = ops.lm_head(hidden_t, w, None, labels if fused_loss else None, ignore_index)
+            else:
+                logits = F.linear(hidden_t[0], w.to(hidden_t.dtype), self.lm_head.bias).float()
+                loss = cross_entropy(logits, labels, ignore_index=ignore_index) if fused_loss else None
+        if labels is not None and loss_weights is not None:
+            loss = weighted_cross_entropy(logits, labels, loss_weights, ignore_index=ignore_index)
+        all_hidden = tuple(engine.from_tframe(h) for h in collect) if collect is not None else None
+        if not return_dict:
+            output = (logits,) + ((all_hidden,) if output_hidden_states else ())
+            return (loss,) + output if loss is not None else output
+        return MaskedLMOutput(loss=loss, logits=logits, hidden_states=all_hidden)
+
+
+class CaduceusForSequenceClassification(CaduceusPreTrainedModel):
+    """modeling_caduceus.py:495-640 (downstream consumer of the backbone)."""
+
+    def __init__(self, config: CaduceusConfig, pooling_strategy: str = "mean", conjoin_train: bool = False,
+                 conjoin_eval: bool = False, device=None, dtype=None, **kwargs):
+        super().__init__(config, **kwargs)
+        if pooling_strategy not in ["mean", "max", "first", "last"]:
+            raise NotImplementedError(f"Pooling strategy `{pooling_strategy}` not implemented.")
+        self.pooling_strategy = pooling_strategy
+        factory_kwargs = {"device": device, "dtype": dtype}
+        self.num_labels = kwargs.get("num_labels", config.num_labels)
+        self.caduceus = Caduceus(config, **factory_kwargs, **kwargs)
+        self.score = nn.Linear(config.d_model, self.num_labels, bias=False)
+        self.conjoin_train = conjoin_train
+        self.conjoin_eval = conjoin_eval
+        self.post_init()
+        self.init_scorer()
+
+    def init_scorer(self, initializer_range=0.02):
+        initializer_range = self.config.initializer_cfg.get("initializer_range", initializer_range) \
+            if self.config.initializer_cfg is not None else initializer_range
+        self.score.weight.data.normal_(std=initializer_range)
+
+    def get_input_embeddings(self):
+        return self.caduceus.backbone.embeddings.word_embeddings
+
+    def set_input_embeddings(self, value):
+        if self.config.rcps:
+            raise NotImplementedError("Setting input embeddings for RCPS LM is not supported.")
+        self.caduceus.backbone.embeddings.word_embeddings = value
+
+    def pool_hidden_states(self, hidden_states, sequence_length_dim=1):
+        """Pools hidden states along sequence length dimension."""
+        if self.pooling_strategy == "mean":
+            return hidden_states.mean(dim=sequence_length_dim)
+        if self.pooling_strategy == "max":
+            return hidden_states.max(dim=sequence_length_dim).values
+        if self.pooling_strategy == "last":
+            return hidden_states.movedim(sequence_length_dim, 0)[-1, ...]
+        if self.pooling_strategy == "first":
+            return hidden_states.movedim(sequence_length_dim, 0)[0, ...]
+
+    def forward(self, input_ids: torch.LongTensor = None, inputs_embeds: Optional[torch.FloatTensor] = None,
+                labels: Optional[torch.LongTensor] = None, output_hidden_states: Optional[bool] = None,
+                return_dict: Optional[bool] = None) -> Union[Tuple, SequenceClassifierOutput]:
+        return_dict = return_dict if return_dict is not None else self._return_dict_default
+        if self.config.rcps:
+            transformer_outputs = self.caduceus(input_ids, inputs_embeds=inputs_embeds,
+                                                output_hidden_states=output_hidden_states, return_dict=return_dict)
+            hs = _first(transformer_outputs)
+            hidden_states = torch.stack([hs[..., :self.config.d_model],
+                                         torch.flip(hs[..., self.config.d_model:], dims=[1, 2])], dim=-1)
+        elif self.conjoin_train or (self.conjoin_eval and not self.training):
+            assert input_ids is not None, "`input_ids` must be provided for conjoining."
+            assert input_ids.ndim == 3, "`input_ids` must be 3D tensor: channels corresponds to forward and rc strands."
+            transformer_outputs = self.caduceus(input_ids[..., 0], inputs_embeds=None,
+                                                output_hidden_states=output_hidden_states, return_dict=return_dict)
+            transformer_outputs_rc = self.caduceus(input_ids[..., 1], inputs_embeds=None,
+                                                   output_hidden_states=output_hidden_states, return_dict=return_dict)
+            hidden_states = torch.stack([_first(transformer_outputs), _first(transformer_outputs_rc)], dim=-1)
+        else:
+            transformer_outputs = self.caduceus(input_ids, inputs_embeds=None,
+                                                output_hidden_states=output_hidden_states, return_dict=return_dict)
+            hidden_states = _first(transformer_outputs)
+        pooled_hidden_states = self.pool_hidden_states(hidden_states)
+        if hidden_states.ndim == 4:
+            wdt = self.score.weight.dtype
+            logits_fwd = self.score(pooled_hidden_states[..., 0].to(wdt))
+            logits_rc = self.score(pooled_hidden_states[..., 1].to(wdt))
+            logits = (logits_fwd + logits_rc) / 2
+        else:
+            logits = self.score(pooled_hidden_states.to(self.score.weight.dtype))
+        loss = None
+        if labels is not None:
+            labels = labels.to(logits.device)
+            if self.config.problem_type is None:
+                if self.num_labels == 1:
+                    self.config.problem_type = "regression"
+                elif self.num_labels > 1 and (labels.dtype == torch.long or labels.dtype == torch.int):
+                    self.config.problem_type = "single_label_classification"
+                else:
+                    self.config.problem_type = "multi_label_classification"
+            if self.config.problem_type == "regression":
+                if self.num_labels == 1:
+                    loss = F.mse_loss(logits.squeeze(), labels.squeeze())
+                else:
+                    loss = F.mse_loss(logits, labels)
+            elif self.config.problem_type == "single_label_classification":
+                loss = F.cross_entropy(logits.view(-1, self.num_labels), labels.view(-1))
+            elif self.config.problem_type == "multi_label_classification":
+                loss = F.binary_cross_entropy_with_logits(logits, labels)
+        if not return_dict:
+            output = (logits,) + tuple(transformer_outputs[1:]) if isinstance(transformer_outputs, tuple) else (logits,)
+            return ((loss,) + output) if loss is not None else output
+        return SequenceClassifierOutput(loss=loss, logits=logits, hidden_states=transformer_outputs.hidden_states)

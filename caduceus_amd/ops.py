@@ -1,0 +1,274 @@
+"""Autograd-aware Python entry points over the C-ABI kernels (include/caduceus_hip.h).
+
+Each function mirrors one interface the reference reaches through its third-party native dependencies
+(mamba_ssm `selective_scan_fn` / `causal_conv1d_fn` / `rms_norm_fn`; call sites cited in the header), but in the
+flip-free "t-frame" / channel-major layouts described in DESIGN.md.  PyTorch is used here only as the owner of device
+memory, streams and the autograd graph; all arithmetic of these ops happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _zeros_like_f32(t, shape=None):
+    return torch.zeros(t.shape if shape is None else shape, dtype=torch.float32, device=t.device)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# embedding
+# ------------------------------------------------------------------------------------------------------------------
+class _Embed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, weight, comp, n_strands, out_dtype):
+        ids = ids.contiguous()
+        w = weight.contiguous()
+        B, Lq = ids.shape
+        V, D = w.shape
+        out = torch.empty((n_strands, B, Lq, D), dtype=out_dtype, device=w.device)
+        stream = L.stream_and_check(ids, w, comp, out)
+        a = L.EmbedArgs(L.ptr(ids), L.ptr(comp), L.ptr(w), L.ptr(out), B, Lq, D, V, n_strands, L.dtype_code(w.dtype),
+                        L.dtype_code(out_dtype))
+        L.check(L.get_lib().cad_embed_fwd(C.byref(a), stream), "cad_embed_fwd")
+        ctx.save_for_backward(ids, comp)
+        ctx.meta = (V, D, n_strands, w.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, comp = ctx.saved_tensors
+        V, D, n_strands, wdt = ctx.meta
+        dout = dout.contiguous()
+        dw = torch.zeros((V, D), dtype=torch.float32, device=dout.device)
+        stream = L.stream_and_check(ids, comp, dout, dw)
+        B, Lq = ids.shape
+        a = L.EmbedBwdArgs(L.ptr(ids), L.ptr(comp), L.ptr(dout), L.ptr(dw), B, Lq, D, V, n_strands,
+                           L.dtype_code(dout.dtype))
+        L.check(L.get_lib().cad_embed_bwd(C.byref(a), stream), "cad_embed_bwd")
+        return None, dw.to(wdt), None, None, None
+
+
+def embed(ids: torch.Tensor, weight: torch.Tensor, comp: Optional[torch.Tensor], n_strands: int,
+          out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """(B, L) int64 ids -> (n_strands, B, L, D) t-frame embedding.  RCPSEmbedding (modeling_rcps.py:46-67)."""
+    if ids.dtype != torch.int64:
+        ids = ids.long()
+    if n_strands == 2 and comp is None:
+        raise AssertionError("Complement map must be provided for RCPS.")  # modeling_caduceus.py:350
+    return _Embed.apply(ids, weight, comp, n_strands, out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fused add + norm
+# ------------------------------------------------------------------------------------------------------------------
+class _AddNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype):
+        x = x.contiguous()
+        S, D = x.shape[0], x.shape[-1]
+        rows = x.numel() // (S * D)
+        w = weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
+        res = None if residual is None else residual.contiguous()
+        if res is not None and res.dtype != torch.float32:
+            raise TypeError("caduceus_amd keeps the residual stream in fp32")
+        y = torch.empty(x.shape, dtype=y_dtype, device=x.device)
+        res_out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        rstd = torch.empty((S * rows,), dtype=torch.float32, device=x.device)
+        mean = None if is_rms else torch.empty((S * rows,), dtype=torch.float32, device=x.device)
+        stream = L.stream_and_check(x, res, w, b, y, res_out, rstd, mean)
+        a = L.AddNormArgs(L.ptr(x), L.ptr(res), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.ptr(mean),
+                          rows, S, D, float(eps), int(is_rms), int(swap_flip), L.dtype_code(x.dtype),
+                          L.dtype_code(y_dtype))
+        L.check(L.get_lib().cad_add_norm_fwd(C.byref(a), stream), "cad_add_norm_fwd")
+        ctx.save_for_backward(res_out, rstd, mean, w)
+        ctx.meta = (rows, S, D, is_rms, swap_flip, x.dtype, y_dtype, residual is not None, bias is not None,
+                    weight.dtype)
+        return y, res_out
+
+    @staticmethod
+    def backward(ctx, dy, dres_out):
+        res_out, rstd, mean, w = ctx.saved_tensors
+        rows, S, D, is_rms, swap_flip, x_dtype, y_dtype, has_res, has_bias, wdt = ctx.meta
+        dy = dy.contiguous()
+        dres_out = None if dres_out is None else dres_out.contiguous()
+        dx = torch.empty(res_out.shape, dtype=x_dtype, device=dy.device)
+        dres_in = torch.empty(res_out.shape, dtype=torch.float32, device=dy.device) if has_res else None
+        dw = torch.zeros((D,), dtype=torch.float32, device=dy.device)
+        db = torch.zeros((D,), dtype=torch.float32, device=dy.device) if has_bias else None
+        stream = L.stream_and_check(dy, dres_out, res_out, rstd, mean, w, dx, dres_in, dw, db)
+        a = L.AddNormBwdArgs(L.ptr(dy), L.ptr(dres_out), L.ptr(res_out), L.ptr(rstd), L.ptr(mean), L.ptr(w), L.ptr(dx),
+                             L.ptr(dres_in), L.ptr(dw), L.ptr(db), rows, S, D, int(is_rms), int(swap_flip),
+                             L.dtype_code(x_dtype), L.dtype_code(y_dtype))
+        L.check(L.get_lib().cad_add_norm_bwd(C.byref(a), stream), "cad_add_norm_bwd")
+        return dx, dres_in, dw.to(wdt), (None if db is None else db.to(wdt)), None, None, None, None
+
+
+def add_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor],
+             eps: float, is_rms: bool, swap_flip: bool, y_dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x: (S, ..., D) t-frame.  Returns (normed in y_dtype, fp32 residual stream) -- rms_norm_fn(prenorm=True) for both
+    strands at once, with the reference's fused-path strand swap as an index map when `swap_flip`."""
+    if swap_flip and x.shape[0] != 2:
+        raise ValueError("swap_flip needs two strands")
+    return _AddNorm.apply(x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# causal conv1d
+# ------------------------------------------------------------------------------------------------------------------
+class _Conv1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, split, rev_lo, rev_hi):
+        x = x.contiguous()
+        E, SB, Lq = x.shape
+        wf = w.float().reshape(E, -1).contiguous()
+        bf = None if bias is None else bias.float().contiguous()
+        out = torch.empty_like(x)
+        stream = L.stream_and_check(x, wf, bf, out)
+        a = L.Conv1dArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(out), SB, Lq, split, E, wf.shape[1], rev_lo, rev_hi,
+                         L.dtype_code(x.dtype))
+        L.check(L.get_lib().cad_conv1d_fwd(C.byref(a), stream), "cad_conv1d_fwd")
+        ctx.save_for_backward(x, wf, bf)
+        ctx.meta = (split, rev_lo, rev_hi, w.shape, w.dtype, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wf, bf = ctx.saved_tensors
+        split, rev_lo, rev_hi, wshape, wdt, has_bias = ctx.meta
+        E, SB, Lq = x.shape
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(wf)
+        db = torch.zeros((E,), dtype=torch.float32, device=x.device) if has_bias else None
+        stream = L.stream_and_check(x, wf, bf, dout, dx, dw, db)
+        a = L.Conv1dBwdArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(dout), L.ptr(dx), L.ptr(dw), L.ptr(db), SB, Lq, split,
+                            E, wf.shape[1], rev_lo, rev_hi, L.dtype_code(x.dtype))
+        L.check(L.get_lib().cad_conv1d_bwd(C.byref(a), stream), "cad_conv1d_bwd")
+        return dx, dw.reshape(wshape).to(wdt), (None if db is None else db.to(wdt)), None, None, None
+
+
+def causal_conv1d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], split: int, rev_lo: int,
+                  rev_hi: int) -> torch.Tensor:
+    """x: (E, SB, L) channel-major.  Depthwise causal conv + SiLU in each row's own direction."""
+    return _Conv1d.apply(x, w, bias, int(split), int(rev_lo), int(rev_hi))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# selective scan
+# ------------------------------------------------------------------------------------------------------------------
+class _Scan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, split, rev_lo, rev_hi):
+        u, delta, Bm, Cm = u.contiguous(), delta.contiguous(), Bm.contiguous(), Cm.contiguous()
+        z = None if z is None else z.contiguous()
+        E, SB, Lq = u.shape
+        N = A.shape[1]
+        Af = A.float().contiguous()
+        Df = D.float().contiguous()
+        bf = delta_bias.float().contiguous()
+        out = torch.empty_like(u)
+        lib = L.get_lib()
+        need_grad = any(ctx.needs_input_grad)
+        state = (torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
+                 if need_grad else None)
+        stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, out, state)
+        if delta.dtype != u.dtype or Bm.dtype != u.dtype or Cm.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
+            raise TypeError("selective_scan: u, delta, B, C, z must share one dtype")
+        a = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
+                       L.ptr(out), L.ptr(state), SB, Lq, split, E, N, rev_lo, rev_hi, L.dtype_code(u.dtype))
+        L.check(lib.cad_scan_fwd(C.byref(a), stream), "cad_scan_fwd")
+        ctx.save_for_backward(u, delta, Af, Bm, Cm, Df, z, bf, state)
+        ctx.meta = (split, rev_lo, rev_hi, A.dtype, D.dtype, delta_bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, delta, Af, Bm, Cm, Df, z, bf, state = ctx.saved_tensors
+        split, rev_lo, rev_hi, Adt, Ddt, bdt = ctx.meta
+        E, SB, Lq = u.shape
+        N = Af.shape[1]
+        dout = dout.contiguous()
+        du, ddelta = torch.empty_like(u), torch.empty_like(u)
+        dz = None if z is None else torch.empty_like(u)
+        dA = torch.zeros_like(Af)
+        dB = torch.zeros((N, SB, Lq), dtype=torch.float32, device=u.device)
+        dC = torch.zeros((N, SB, Lq), dtype=torch.float32, device=u.device)
+        dD = torch.zeros_like(Df)
+        dbias = torch.zeros_like(bf)
+        stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dB, dC, dD, dbias)
+        a = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
+                          L.ptr(dout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz), L.ptr(dA), L.ptr(dB),
+                          L.ptr(dC), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N, rev_lo, rev_hi,
+                          L.dtype_code(u.dtype))
+        L.check(L.get_lib().cad_scan_bwd(C.byref(a), stream), "cad_scan_bwd")
+        return (du, ddelta, dA.to(Adt), dB.to(u.dtype), dC.to(u.dtype), dD.to(Ddt), dz, dbias.to(bdt), None, None,
+                None)
+
+
+def selective_scan(u, delta, A, Bm, Cm, D, z, delta_bias, split: int, rev_lo: int, rev_hi: int) -> torch.Tensor:
+    """u, delta, z: (E, SB, L); A: (E, N) (= -exp(A_log)); Bm, Cm: (N, SB, L); D, delta_bias: (E).
+    mamba_ssm `selective_scan_fn(..., delta_softplus=True)` per row in its own direction."""
+    return _Scan.apply(u, delta, A, Bm, Cm, D, z, delta_bias, int(split), int(rev_lo), int(rev_hi))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LM head (+ masked cross entropy)
+# ------------------------------------------------------------------------------------------------------------------
+class _LmHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, weight, comp, labels, ignore_index):
+        hidden = hidden.contiguous()
+        S, D = hidden.shape[0], hidden.shape[-1]
+        rows = hidden.numel() // (S * D)
+        w = weight.float().contiguous()
+        V = w.shape[0]
+        logits = torch.empty(hidden.shape[1:-1] + (V,), dtype=torch.float32, device=hidden.device)
+        lab = None if labels is None else labels.reshape(-1).long().contiguous()
+        acc = torch.zeros((2,), dtype=torch.float32, device=hidden.device)
+        stream = L.stream_and_check(hidden, w, comp, lab, logits, acc)
+        a = L.LmHeadArgs(L.ptr(hidden), L.ptr(w), L.ptr(comp), L.ptr(lab), L.ptr(logits), C.c_void_p(acc.data_ptr()),
+                         C.c_void_p(acc.data_ptr() + 4), rows, D, V, S, int(ignore_index), L.dtype_code(hidden.dtype))
+        L.check(L.get_lib().cad_lm_head_fwd(C.byref(a), stream), "cad_lm_head_fwd")
+        loss = acc[0] / acc[1] if labels is not None else acc[0]
+        ctx.save_for_backward(hidden, w, comp, lab, logits, acc)
+        ctx.meta = (ignore_index, weight.dtype, labels is not None)
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, dlogits, dloss):
+        hidden, w, comp, lab, logits, acc = ctx.saved_tensors
+        ignore_index, wdt, has_labels = ctx.meta
+        S, D = hidden.shape[0], hidden.shape[-1]
+        V = w.shape[0]
+        g = torch.zeros((logits.numel() // V, V), dtype=torch.float32, device=hidden.device)
+        if dlogits is not None:
+            g = g + dlogits.reshape(-1, V)
+        if has_labels and dloss is not None:
+            valid = lab != ignore_index
+            sm = torch.softmax(logits.reshape(-1, V), dim=-1)
+            sm[torch.arange(sm.shape[0], device=sm.device)[valid], lab[valid]] -= 1.0
+            sm = sm * (valid.to(sm.dtype) * (dloss / acc[1])).unsqueeze(1)
+            g = g + sm
+        gt = g.to(hidden.dtype)
+        h = hidden.reshape(S, -1, D)
+        dh = torch.empty_like(h)
+        wt = w.to(hidden.dtype)
+        dh[0] = gt @ wt
+        dw = gt.t().float() @ h[0].float() if h.dtype == torch.float32 else (gt.t() @ h[0]).float()
+        if S == 2:
+            dh[1] = gt @ wt[comp]
+            d2 = (gt.t() @ h[1]).float()
+            dw.index_add_(0, comp, d2)
+        return dh.reshape(hidden.shape), dw.to(wdt), None, None, None
+
+
+def lm_head(hidden: torch.Tensor, weight: torch.Tensor, comp: Optional[torch.Tensor],
+            labels: Optional[torch.Tensor] = None, ignore_index: int = -100):
+    """hidden: (S, B, L, D) t-frame -> (fp32 logits (B, L, V), loss or None).  RCPSLMHead + cross_entropy."""
+    logits, loss = _LmHead.apply(hidden, weight, comp, labels, ignore_index)
+    return logits, (loss if labels is not None else None)

@@ -1,0 +1,253 @@
+/* caduceus_hip.h  --  C-ABI of libcaduceus_hip.so: the MI355X (gfx950) kernels behind the Caduceus hot path.
+ *
+ * Boundary rules:
+ *   - plain C, raw DEVICE pointers + sizes + a hipStream_t passed as void*; no torch / C++ types;
+ *   - the caller (PyTorch's allocator, or any other runtime) owns every buffer; kernels never allocate;
+ *   - every entry point returns an int status: 0 = ok, non-zero = cad_status (caller raises);
+ *   - launches are asynchronous on the given stream, re-entrant, no global mutable state except the opt-in
+ *     profiler (cad_prof_*).
+ *
+ * Each entry point states which interface of the reference it replaces.  The reference itself is pure Python
+ * (the .py files under /root/reference/caduceus/) and reaches native code only through the third-party, un-vendored packages
+ * mamba-ssm==1.2.0.post1 / causal-conv1d==1.2.0.post2 (/root/reference/caduceus_env.yml:46-50); the cited
+ * file:line are the reference's call sites of those.
+ *
+ * Layout conventions
+ *   "t-frame"  : the RCPS stream (B, L, 2*D) of the reference is held as n_strands=2 separate D-wide strands,
+ *                tensor (S, B, L, D) row-major, strand 1 stored with its CHANNELS REVERSED
+ *                (t2[c] = ref[..., 2D-1-c]).  In this frame both strands use every weight in natural order and
+ *                differ only in scan direction, so all reference flips/cats become index maps.
+ *                Caduceus-Ph has S=1.
+ *   rows "SB"  : S*B independent sequences ("rows").  Rows [0, split) run in direction rev_lo, rows
+ *                [split, SB) in direction rev_hi (0 = left-to-right, 1 = right-to-left along L).
+ *   channel-major activations: (E, SB, L) row-major, i.e. L contiguous -- the layout the in_proj GEMM writes
+ *                and the scan reads with coalesced loads along L.
+ */
+#ifndef CADUCEUS_HIP_H
+#define CADUCEUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CAD_OK = 0, CAD_ERR_BAD_ARG = 1, CAD_ERR_UNSUPPORTED = 2, CAD_ERR_LAUNCH = 3 } cad_status;
+typedef enum { CAD_F32 = 0, CAD_BF16 = 1 } cad_dtype;
+
+/* Library identification / error text (static strings). */
+const char* cad_version(void);
+const char* cad_status_string(int status);
+/* 1 when built for the GPU (hipcc, gfx950); 0 for the host-emulator build used only by the test-suite. */
+int cad_is_device_build(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RCPS / plain embedding gather.   Replaces RCPSEmbedding.forward/.rc (modeling_rcps.py:46-67) and
+ * nn.Embedding (modeling_caduceus.py:157).
+ *   out[0][b][l][:] = W[ids[b][l]][:]                       strand 0
+ *   out[1][b][l][:] = W[comp[ids[b][l]]][:]                 strand 1 (t-frame: the reference's two flipL
+ *                                                            cancel and its flipC is the storage convention)
+ * Integer index path is exact.  ids: int64 (B, L).  comp: int64 (V) device, NULL when n_strands == 1.
+ * W: (V, D) in w_dtype.  out: (n_strands, B, L, D) in out_dtype.
+ * Returns CAD_ERR_BAD_ARG if an id is outside [0, V) (checked on device, reported via *err_flag if given). */
+typedef struct {
+    const int64_t* ids;
+    const int64_t* comp;
+    const void* weight;
+    void* out;
+    int64_t B, L;
+    int D, V, n_strands;
+    int w_dtype, out_dtype;
+} cad_embed_args;
+int cad_embed_fwd(const cad_embed_args* a, void* stream);
+/* dW (V, D) fp32 is ACCUMULATED into (caller zeroes):  dW[ids] += dout[0], dW[comp[ids]] += dout[1]. */
+typedef struct {
+    const int64_t* ids;
+    const int64_t* comp;
+    const void* dout;
+    float* dweight;
+    int64_t B, L;
+    int D, V, n_strands;
+    int dout_dtype;
+} cad_embed_bwd_args;
+int cad_embed_bwd(const cad_embed_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused residual-add + RMSNorm / LayerNorm over both strands.   Replaces mamba_ssm rms_norm_fn / layer_norm_fn
+ * as called by RCPSMambaBlock.forward (modeling_rcps.py:170-197), RCPSAddNormWrapper (:107-130),
+ * mamba_ssm Block (modeling_caduceus.py:64) and the final norm (modeling_caduceus.py:233-273).
+ *   sum = x (+ residual_in)        fp32
+ *   y   = norm(sum) * w (+ b)      fp32 statistics
+ * x, y: (S, R, D) with R = rows_per_strand = B*L tokens.   swap_flip = 1 reproduces the reference's FUSED-path
+ * quirk (modeling_rcps.py:177-197: the "fwd" norm is fed the second half, the "rc" norm the first): in the
+ * t-frame the outputs go to the OTHER strand with channels reversed:
+ *   y[1-s][r][D-1-c], residual_out[1-s][r][D-1-c]  <-  token (s, r), channel c.
+ * swap_flip = 0 is the un-fused / final-norm / Caduceus-Ph behaviour (identity map).
+ * residual_in may be NULL (first layer).  residual_out (fp32) and rstd (S*R floats) [+ mean for LayerNorm] are
+ * always written; they are what the backward needs.  weight/bias fp32 (bias NULL for RMSNorm). */
+typedef struct {
+    const void* x;
+    const float* residual_in;
+    const float* weight;
+    const float* bias;
+    void* y;
+    float* residual_out;
+    float* rstd;
+    float* mean;
+    int64_t rows_per_strand;
+    int n_strands, D;
+    float eps;
+    int is_rms, swap_flip;
+    int x_dtype, y_dtype;
+} cad_add_norm_args;
+int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream);
+/* Backward.  dy (y_dtype) and dres_out (fp32, may be NULL) are in the OUTPUT index space, sum_saved/rstd/mean
+ * as written by the forward (sum_saved = residual_out, output index space).  Writes dx (x_dtype) and, if not
+ * NULL, dres_in (fp32) in the INPUT index space; ACCUMULATES dweight/dbias (fp32, caller zeroes). */
+typedef struct {
+    const void* dy;
+    const float* dres_out;
+    const float* sum_saved;
+    const float* rstd;
+    const float* mean;
+    const float* weight;
+    void* dx;
+    float* dres_in;
+    float* dweight;
+    float* dbias;
+    int64_t rows_per_strand;
+    int n_strands, D;
+    int is_rms, swap_flip;
+    int x_dtype, y_dtype;
+} cad_add_norm_bwd_args;
+int cad_add_norm_bwd(const cad_add_norm_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Depthwise causal conv1d (+bias, +SiLU) along L, channel-major, with per-row direction.
+ * Replaces causal_conv1d_cuda.causal_conv1d_fwd/bwd reached through mamba_ssm.Mamba.forward
+ * (modeling_caduceus.py:128,130).  In logical (direction-mapped) coordinates:
+ *   out[p] = silu(bias + sum_k w[k] * x[p - (K-1) + k]),  zero padding before the logical start.
+ * A right-to-left row is therefore the reference's flipL -> conv -> flipL without moving data.
+ * x, out: (E, SB, L) in dtype.  w: (E, K) fp32, K in [1, 4].  bias: (E) fp32 or NULL. */
+typedef struct {
+    const void* x;
+    const float* w;
+    const float* bias;
+    void* out;
+    int64_t SB, L, split;
+    int E, K;
+    int rev_lo, rev_hi;
+    int dtype;
+} cad_conv1d_args;
+int cad_conv1d_fwd(const cad_conv1d_args* a, void* stream);
+/* dx is WRITTEN (dtype); dw (E,K) and dbias (E) fp32 are ACCUMULATED (caller zeroes). */
+typedef struct {
+    const void* x;
+    const float* w;
+    const float* bias;
+    const void* dout;
+    void* dx;
+    float* dw;
+    float* dbias;
+    int64_t SB, L, split;
+    int E, K;
+    int rev_lo, rev_hi;
+    int dtype;
+} cad_conv1d_bwd_args;
+int cad_conv1d_bwd(const cad_conv1d_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Selective SSM scan, one direction per row.   Replaces selective_scan_cuda.fwd / .bwd reached through
+ * mamba_ssm.Mamba.forward -> mamba_inner_fn (modeling_caduceus.py:128,130):
+ *   dt   = softplus(delta + delta_bias)                           fp32
+ *   h_p  = exp(dt_p * A) * h_{p-1} + dt_p * B_p * u_p             fp32 state (E x N), h_{-1} = 0
+ *   y_p  = <C_p, h_p> + D * u_p ;   out_p = y_p * silu(z_p)       (z NULL -> no gate)
+ * p is the logical position; physical l = p (left-to-right rows) or L-1-p (right-to-left rows).  The
+ * right-to-left variant is an exact mirror (same chunk boundaries counted from the logical start, same
+ * floating-point operation order), which is what keeps RC-equivariance bit-exact.
+ * u, delta, z, out: (E, SB, L) dtype.  A: (E, N) fp32 (= -exp(A_log)).  Bm, Cm: (N, SB, L) dtype.
+ * D, delta_bias: (E) fp32.  chunk_state: fp32 buffer of cad_scan_state_floats() elements (the running state at
+ * every chunk start, needed by the backward), or NULL for inference. */
+typedef struct {
+    const void* u;
+    const void* delta;
+    const float* A;
+    const void* Bm;
+    const void* Cm;
+    const float* D;
+    const void* z;
+    const float* delta_bias;
+    void* out;
+    float* chunk_state;
+    int64_t SB, L, split;
+    int E, N;
+    int rev_lo, rev_hi;
+    int dtype;
+} cad_scan_args;
+int cad_scan_fwd(const cad_scan_args* a, void* stream);
+int64_t cad_scan_chunk_len(void);
+int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
+/* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E), dB, dC ((N,SB,L) fp32) are
+ * ACCUMULATED with fp32 atomics (caller zeroes; summation order over channels is not deterministic). */
+typedef struct {
+    const void* u;
+    const void* delta;
+    const float* A;
+    const void* Bm;
+    const void* Cm;
+    const float* D;
+    const void* z;
+    const float* delta_bias;
+    const void* dout;
+    const float* chunk_state;
+    void* du;
+    void* ddelta;
+    void* dz;
+    float* dA;
+    float* dB;
+    float* dC;
+    float* dD;
+    float* ddelta_bias;
+    int64_t SB, L, split;
+    int E, N;
+    int rev_lo, rev_hi;
+    int dtype;
+} cad_scan_bwd_args;
+int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()
+ * (modeling_caduceus.py:475) and cross_entropy(ignore_index) (modeling_caduceus.py:279-283,
+ * src/tasks/metrics.py:181-184).  t-frame:  logits[b,l,v] = <W[v], t1[b,l]> + <W[comp[v]], t2[b,l]>.
+ * hidden: (S, B*L, D) dtype.  W: (V, D) fp32.  logits: (B*L, V) fp32 (always written).
+ * If labels != NULL: loss_sum[0] += sum over tokens with label != ignore_index of -log softmax[label],
+ * count[0] += number of such tokens (both ACCUMULATED; caller zeroes; loss = loss_sum / count). */
+typedef struct {
+    const void* hidden;
+    const float* weight;
+    const int64_t* comp;
+    const int64_t* labels;
+    float* logits;
+    float* loss_sum;
+    float* count;
+    int64_t rows;
+    int D, V, n_strands;
+    int64_t ignore_index;
+    int dtype;
+} cad_lm_head_args;
+int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Opt-in kernel timer (HIP events on the launch stream) used by bench.py for the roofline line.
+ * kind: 0 scan_fwd, 1 scan_bwd, 2 conv_fwd, 3 conv_bwd, 4 add_norm_fwd, 5 add_norm_bwd, 6 embed, 7 lm_head. */
+#define CAD_PROF_KINDS 8
+int cad_prof_enable(int on);
+int cad_prof_reset(void);
+/* Synchronises the recorded events.  Outputs total milliseconds and number of launches of that kind. */
+int cad_prof_read(int kind, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CADUCEUS_HIP_H */

@@ -36,3 +36,22 @@ MODEL_VARIANTS = ["ps_fused", "ps_unfused", "ph_fused", "ph_unfused", "ps_fused_
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- kernel backends ---------------------------------------------------------------------------------------------
+# "emu": the kernel sources compiled for the host emulator (tests/emu), CPU tensors -- runs in the build container.
+# "hip": the real gfx950 library on cuda:0 -- the parity tests proper (pytest -m gpu on the MI355X box).
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    from caduceus_amd import _lib
+    if request.param == "emu":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        from build_emu import build_emu
+        _lib.use_library_for_testing(build_emu())
+        yield "emu", torch.device("cpu")
+        _lib.use_library_for_testing(None)
+    else:
+        _lib.use_library_for_testing(None)
+        assert torch.cuda.is_available(), "gpu-marked test without a GPU"
+        assert _lib.is_device_build(), "libcaduceus_hip.so must be the gfx950 build"
+        yield "hip", torch.device("cuda:0")

@@ -1,0 +1,41 @@
+"""Build the HOST-EMULATOR flavour of the kernel library (tests only; see emu_runtime.h)."""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "caduceus_amd", "csrc")
+LIB = os.path.join(HERE, "libcaduceus_emu.so")
+
+
+def build_emu(force: bool = False) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "emu_runtime.*")) + \
+        [os.path.join(ROOT, "include", "caduceus_hip.h")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-DCAD_EMU", "-I", HERE, "-Wno-attributes", "-Wno-unknown-pragmas"]
+    procs = []
+    for s in srcs:
+        obj = os.path.join(objdir, os.path.basename(s) + ".o")
+        procs.append((s, obj, subprocess.Popen(["g++", *flags, "-x", "c++", "-c", s, "-o", obj],
+                                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    rt = os.path.join(objdir, "emu_runtime.o")
+    procs.append((os.path.join(HERE, "emu_runtime.cpp"), rt,
+                  subprocess.Popen(["g++", *flags, "-c", os.path.join(HERE, "emu_runtime.cpp"), "-o", rt],
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    objs = []
+    for s, obj, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"g++ (emu) failed for {s}:\n{out.decode()}")
+        objs.append(obj)
+    subprocess.check_call(["g++", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_emu(force=True))

@@ -1,0 +1,219 @@
+"""Per-kernel parity of the C-ABI ops against the CPU oracle, on the host emulator (CPU) and on the GPU (-m gpu).
+Edge cases follow the reference tests' spirit: ragged / tiny / multi-chunk lengths, both directions, odd d_state."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from caduceus_amd import ops
+from oracle import oracle_model as om
+
+def leaf(t, dev, dtype=None):
+    """Fresh leaf copy on the backend device (never aliases the CPU master tensor)."""
+    t = t.detach().clone().to(dev)
+    return (t if dtype is None else t.to(dtype)).requires_grad_(True)
+
+
+FP32 = dict(rtol=6e-4, atol=2e-3)   # reference tolerance triple (caduceus/tests/test_rcps.py:34-36)
+BF16 = dict(rtol=3e-2, atol=5e-2)
+
+
+def _rows_oracle(fn, tensors_rowdim1, split, rev_lo, rev_hi):
+    """Apply a (1, C, L)-shaped oracle `fn` row by row with the row's direction realised by explicit flips."""
+    SB = tensors_rowdim1[0].shape[1]
+    outs = []
+    for sb in range(SB):
+        rev = rev_lo if sb < split else rev_hi
+        f = (lambda t: t.flip(-1)) if rev else (lambda t: t)
+        outs.append(f(fn(*[f(t[:, sb]).unsqueeze(0) for t in tensors_rowdim1])[0]))
+    return torch.stack(outs, 1)
+
+
+SCAN_CASES = [  # E, SB, L, N, split, rev_lo, rev_hi
+    (4, 1, 64, 16, 1, 0, 0),
+    (6, 2, 100, 16, 1, 0, 1),
+    (3, 2, 37, 8, 1, 1, 0),
+    (5, 1, 1100, 16, 0, 0, 1),
+    (2, 1, 1, 3, 1, 0, 0),
+    (9, 3, 2064, 16, 2, 1, 0),
+]
+
+
+def _scan_inputs(E, SB, L, N, seed, device, dtype):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    t = dict(u=r(E, SB, L), delta=r(E, SB, L), A=-(0.5 + 15.5 * torch.rand(E, N, generator=g)), B=r(N, SB, L),
+             C=r(N, SB, L), D=r(E), z=r(E, SB, L), bias=r(E) - 3.0, w=r(E, SB, L))
+    for k in ("u", "delta", "B", "C", "z", "w"):
+        t[k] = t[k].to(dtype).float()  # oracle sees exactly the values the kernel sees
+    return t
+
+
+@pytest.mark.parametrize("case", SCAN_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_selective_scan_fwd_bwd(backend, case, dtype):
+    name, dev = backend
+    E, SB, L, N, split, rl, rh = case
+    t = _scan_inputs(E, SB, L, N, 11, dev, dtype)
+    order = ("u", "delta", "A", "B", "C", "D", "z", "bias")
+    act = {"u", "delta", "B", "C", "z"}
+    ins = [leaf(t[k], dev, dtype if k in act else torch.float32) for k in order]
+    out = ops.selective_scan(*ins, split, rl, rh)
+    (out.float() * t["w"].to(dev)).sum().backward()
+    ref_ins = [leaf(t[k], 'cpu') for k in order]
+    u, d, A, B, C, D, z, b = ref_ins
+    ref = _rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, A, B_, C_, D, z_, b), [u, d, B, C, z],
+                       split, rl, rh)
+    (ref * t["w"]).sum().backward()
+    tol = FP32 if dtype == torch.float32 else BF16
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), **tol)
+    for k, a, r in zip(order, ins, ref_ins):
+        scale = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.float().cpu(), r.grad, rtol=tol["rtol"], atol=tol["atol"] * scale,
+                                   msg=lambda m, k=k: f"d{k}: {m}")
+
+
+@pytest.mark.parametrize("shape", ["1x64x64x16", "2x32x200x16", "1x16x37x8"])
+def test_selective_scan_golden(backend, shape, golden_dir):
+    """Against the committed third-party (HF mamba torch path) vectors, batch-major -> channel-major."""
+    name, dev = backend
+    z = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/scan_op_{shape}.npz").items()}
+    cm = lambda t: t.permute(1, 0, 2).contiguous()
+    ins = [cm(z["u"]), cm(z["delta"]), z["A"], cm(z["B"]), cm(z["C"]), z["D"], cm(z["z"]), z["delta_bias"]]
+    ins = [leaf(t, dev) for t in ins]
+    out = ops.selective_scan(*ins, ins[0].shape[1], 0, 0)
+    torch.testing.assert_close(cm(out.cpu().detach()), z["out"], **FP32)
+    (out * cm(z["dout"]).to(dev)).sum().backward()
+    for a, k, is_cm in zip(ins, ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias"),
+                           (1, 1, 0, 1, 1, 0, 1, 0)):
+        got = a.grad.cpu()
+        got = cm(got) if is_cm else got
+        torch.testing.assert_close(got, z[k], rtol=6e-4, atol=2e-3 * max(1.0, float(z[k].abs().max())))
+
+
+@pytest.mark.parametrize("case", [(5, 2, 75, 4, 1, 0, 1), (3, 1, 8, 4, 1, 1, 1), (4, 3, 2100, 3, 1, 0, 1),
+                                  (2, 1, 1, 4, 0, 0, 0), (6, 2, 4096, 2, 2, 1, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_causal_conv1d(backend, case, dtype):
+    name, dev = backend
+    E, SB, L, K, split, rl, rh = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(E, SB, L, generator=g).to(dtype).float()
+    w = 0.5 * torch.randn(E, 1, K, generator=g)
+    b = 0.2 * torch.randn(E, generator=g)
+    dout = torch.randn(E, SB, L, generator=g)
+    ins = [leaf(x, dev, dtype), leaf(w, dev), leaf(b, dev)]
+    out = ops.causal_conv1d(*ins, split, rl, rh)
+    (out.float() * dout.to(dev)).sum().backward()
+    rx, rw, rb = leaf(x, 'cpu'), leaf(w, 'cpu'), leaf(b, 'cpu')
+    ref = _rows_oracle(lambda x_: om.causal_conv1d_silu(x_, rw.squeeze(1), rb), [rx], split, rl, rh)
+    (ref * dout).sum().backward()
+    tol = FP32 if dtype == torch.float32 else BF16
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), **tol)
+    torch.testing.assert_close(ins[0].grad.float().cpu(), rx.grad, **tol)
+    torch.testing.assert_close(ins[1].grad.cpu(), rw.grad, rtol=tol["rtol"], atol=tol["atol"] * max(1, L / 64))
+    torch.testing.assert_close(ins[2].grad.cpu(), rb.grad, rtol=tol["rtol"], atol=tol["atol"] * max(1, L / 64))
+
+
+def test_causal_conv1d_golden(backend, golden_dir):
+    name, dev = backend
+    z = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/conv_op.npz").items()}
+    cm = lambda t: t.permute(1, 0, 2).contiguous()
+    x, w, b = leaf(cm(z["x"]), dev), leaf(z["w"].unsqueeze(1), dev), leaf(z["b"], dev)
+    out = ops.causal_conv1d(x, w, b, x.shape[1], 0, 0)
+    torch.testing.assert_close(cm(out.detach().cpu()), z["out"], **FP32)
+    (out * cm(z["dout"]).to(dev)).sum().backward()
+    torch.testing.assert_close(cm(x.grad.cpu()), z["dx"], **FP32)
+    torch.testing.assert_close(w.grad.cpu().squeeze(1), z["dw"], **FP32)
+    torch.testing.assert_close(b.grad.cpu(), z["db"], **FP32)
+
+
+def _ref_add_norm(x, res, w, b, eps, is_rms, swap_flip):
+    """Reference-frame restatement on the t-frame tensors: strands swap and channels flip when `swap_flip`."""
+    y, s = om.add_norm(x, w if not swap_flip else w, b, res, eps, is_rms)
+    if swap_flip:
+        # kernel: out[1-s][..., D-1-c] = w[D-1-c] * xhat[s][..., c]
+        xh, _ = om.add_norm(x, torch.ones_like(w), None, res, eps, is_rms)
+        y = xh.flip(0).flip(-1) * w
+        if b is not None:
+            y = y + b
+        s = s.flip(0).flip(-1)
+    return y, s
+
+
+@pytest.mark.parametrize("S,R,D", [(2, 37, 32), (1, 64, 256), (2, 5, 130), (2, 16, 1024)])
+@pytest.mark.parametrize("is_rms", [True, False])
+@pytest.mark.parametrize("swap_flip", [False, True])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+def test_add_norm(backend, S, R, D, is_rms, swap_flip, xdt, ydt):
+    name, dev = backend
+    if swap_flip and S == 1:
+        pytest.skip("swap needs two strands")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(S, 1, R, D, generator=g).to(xdt).float()
+    for has_res in (False, True):
+        res = torch.randn(S, 1, R, D, generator=g) if has_res else None
+        w = 1 + 0.2 * torch.randn(D, generator=g)
+        b = None if is_rms else 0.1 * torch.randn(D, generator=g)
+        gy, gr = torch.randn(S, 1, R, D, generator=g), torch.randn(S, 1, R, D, generator=g)
+        ins = [leaf(x, dev, xdt), None if res is None else leaf(res, dev), leaf(w, dev),
+               None if b is None else leaf(b, dev)]
+        y, s = ops.add_norm(ins[0], ins[1], ins[2], ins[3], 1e-5, is_rms, swap_flip, ydt)
+        ((y.float() * gy.to(dev)).sum() + (s * gr.to(dev)).sum()).backward()
+        rins = [leaf(x, 'cpu'), None if res is None else leaf(res, 'cpu'), leaf(w, 'cpu'),
+                None if b is None else leaf(b, 'cpu')]
+        ry, rs = _ref_add_norm(rins[0], rins[1], rins[2], rins[3], 1e-5, is_rms, swap_flip)
+        ((ry * gy).sum() + (rs * gr).sum()).backward()
+        tol = FP32 if ydt == torch.float32 else BF16
+        torch.testing.assert_close(y.float().cpu(), ry.detach(), **tol)
+        torch.testing.assert_close(s.cpu(), rs.detach(), **FP32)
+        for a, r in zip(ins, rins):
+            if a is not None:
+                sc = max(1.0, float(r.grad.abs().max()))
+                torch.testing.assert_close(a.grad.float().cpu(), r.grad, rtol=tol["rtol"], atol=tol["atol"] * sc)
+
+
+@pytest.mark.parametrize("n_strands", [1, 2])
+def test_embed(backend, n_strands):
+    name, dev = backend
+    g = torch.Generator().manual_seed(0)
+    V, D, B, L = 16, 48, 3, 700
+    ids = torch.randint(0, V, (B, L), generator=g)
+    comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15])
+    W = torch.randn(V, D, generator=g)
+    w = leaf(W, dev)
+    out = ops.embed(ids.to(dev), w, comp.to(dev) if n_strands == 2 else None, n_strands)
+    ref = torch.stack([W[ids]] + ([W[comp[ids]]] if n_strands == 2 else []), 0)
+    assert torch.equal(out.cpu(), ref)  # integer index path: exact
+    gout = torch.randn(out.shape, generator=g)
+    (out * gout.to(dev)).sum().backward()
+    rw = leaf(W, 'cpu')
+    rref = torch.stack([rw[ids]] + ([rw[comp[ids]]] if n_strands == 2 else []), 0)
+    (rref * gout).sum().backward()
+    torch.testing.assert_close(w.grad.cpu(), rw.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("n_strands", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lm_head_and_loss(backend, n_strands, dtype):
+    name, dev = backend
+    g = torch.Generator().manual_seed(2)
+    V, D, B, L = 16, 40, 2, 300
+    comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15])
+    W = torch.randn(V, D, generator=g)
+    h = torch.randn(n_strands, B, L, D, generator=g).to(dtype).float()
+    labels = torch.randint(0, V, (B, L), generator=g)
+    labels[torch.rand(B, L, generator=g) < 0.8] = 4
+    hd, wd = leaf(h, dev, dtype), leaf(W, dev)
+    logits, loss = ops.lm_head(hd, wd, comp.to(dev) if n_strands == 2 else None, labels.to(dev), 4)
+    (loss + 0.01 * logits.square().mean()).backward()
+    rh, rw = leaf(h, 'cpu'), leaf(W, 'cpu')
+    rl = F.linear(rh[0], rw) + (F.linear(rh[1], rw[comp]) if n_strands == 2 else 0)
+    rloss = om.cross_entropy(rl, labels, 4)
+    (rloss + 0.01 * rl.square().mean()).backward()
+    tol = FP32 if dtype == torch.float32 else BF16
+    torch.testing.assert_close(logits.cpu(), rl.detach(), **FP32)
+    torch.testing.assert_close(loss.cpu(), rloss.detach(), **FP32)
+    torch.testing.assert_close(hd.grad.float().cpu(), rh.grad, **tol)
+    torch.testing.assert_close(wd.grad.cpu(), rw.grad, rtol=tol["rtol"], atol=tol["atol"])
