@@ -1,0 +1,204 @@
+"""Headline benchmark: DNA tokens/s of one hg38-style MLM pre-training step (forward + backward + gradient all-reduce +
+clip + AdamW) of Caduceus-PS d_model=256 n_layer=16 at seqlen 131072, bf16 compute, one sequence per GPU
+(BASELINE.json configs[2] at N=1, configs[3] at N=8; /root/reference/slurm_scripts/run_pretrain_caduceus.sh:19-60).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (the selective scan) from HIP-event timings
+taken inside the timed region; `cpu_baseline` times the CPU oracle (C/OpenMP scan + torch CPU GEMMs) on a bounded
+sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+COMP = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 6, 7: 10, 8: 9, 9: 8, 10: 7, 11: 11}  # tokenization_caduceus.py:49-66
+SSM_CFG = dict(d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=1e-3, dt_max=0.1, dt_init="random",
+               dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False, use_fast_path=True)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guide: 8.0 TB/s; 6.29 TB/s measured streaming copy)
+
+
+def make_config(d_model, n_layer, rcps=True):
+    from caduceus_amd import CaduceusConfig
+    return CaduceusConfig(d_model=d_model, n_layer=n_layer, vocab_size=12, ssm_cfg=dict(SSM_CFG), rms_norm=True,
+                          residual_in_fp32=False, fused_add_norm=True, pad_vocab_size_multiple=8, norm_epsilon=1e-5,
+                          initializer_cfg=dict(initializer_range=0.02, rescale_prenorm_residual=True,
+                                               n_residuals_per_layer=1),
+                          bidirectional=True, bidirectional_strategy="add", bidirectional_weight_tie=True, rcps=rcps,
+                          complement_map=dict(COMP), pad_token_id=4)
+
+
+def synthetic_batch(gen, B, L, device):
+    """uniform A/C/G/T (ids 7..10), 0.1% N -> pad(4); MLM corruption of
+    src/dataloaders/utils/mlm.py:4-32 (15% targets: 80% [MASK]=3, 10% random id, 10% unchanged; other labels = 4)."""
+    ids = torch.randint(7, 11, (B, L), generator=gen)
+    ids[torch.rand(B, L, generator=gen) < 0.001] = 4
+    labels = ids.clone()
+    tgt = torch.rand(B, L, generator=gen) < 0.15
+    labels[~tgt] = 4
+    r = torch.rand(B, L, generator=gen)
+    ids = ids.clone()
+    ids[tgt & (r < 0.8)] = 3
+    rnd = tgt & (r >= 0.8) & (r < 0.9)
+    ids[rnd] = torch.randint(0, 12, (int(rnd.sum()),), generator=gen)
+    return ids.to(device), labels.to(device)
+
+
+def cpu_baseline(d_model, n_layer, sample_len):
+    """The oracle (reference formulation, fp32) on the host cores: fwd + bwd of the same model on a bounded sample."""
+    from caduceus_amd import CaduceusForMaskedLM
+    from oracle import oracle_model as om
+    from oracle import oracle_ops
+    torch.manual_seed(2222)
+    cfgobj = make_config(d_model, n_layer)
+    model = CaduceusForMaskedLM(cfgobj)  # parameter container only (CPU); arithmetic below is the oracle's
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v)
+          for k, v in model.state_dict().items()}
+    cfg = dict(rcps=True, fused_add_norm=True, rms_norm=True, norm_epsilon=1e-5, n_layer=n_layer, bidirectional=True,
+               bidirectional_strategy="add")
+    ids, labels = synthetic_batch(torch.Generator().manual_seed(1), 1, sample_len, "cpu")
+    om.set_scan_backend(oracle_ops.selective_scan_c)
+    try:
+        t0 = time.perf_counter()
+        out = om.masked_lm_forward(sd, ids, cfg, labels=labels, ignore_index=4)
+        out["loss"].backward()
+        dt = time.perf_counter() - t0
+    finally:
+        om.set_scan_backend(None)
+    return {"value": sample_len / dt, "unit": "tokens/s", "cores": max(oracle_ops.num_threads(), torch.get_num_threads()),
+            "kind": "port",
+            "sample": f"1 x {sample_len} tokens, fwd+bwd of the same model (fp32, oracle/oracle_model.py + "
+                      f"oracle/cad_oracle.c OpenMP scan), {dt:.1f} s, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seqlen", type=int, default=131072)
+    ap.add_argument("--d-model", type=int, default=256)
+    ap.add_argument("--n-layer", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=1, help="sequences per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="tokens of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from caduceus_amd import CaduceusForMaskedLM, _lib
+    from caduceus_amd.dp import BucketedGradReducer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+
+    torch.manual_seed(2222)  # configs/experiment/hg38/hg38.yaml:54; identical initial weights on every rank
+    model = CaduceusForMaskedLM(make_config(args.d_model, args.n_layer)).to(dev).train()
+    n_params = sum(p.numel() for p in model.parameters())
+    reducer = BucketedGradReducer(model.parameters())
+    decay, no_decay = [], []
+    for n_, p in model.named_parameters():  # src/utils/optim_groups.py:25-38 semantics
+        (no_decay if (n_.endswith("bias") or getattr(p, "_no_weight_decay", False) or "embedding" in n_) else decay
+         ).append(p)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}],
+                            lr=8e-3, betas=(0.9, 0.95), fused=True)
+    amp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    gen = torch.Generator().manual_seed(2222 + rank)
+    batches = [synthetic_batch(gen, args.batch, args.seqlen, dev) for _ in range(min(4, args.steps + args.warmup))]
+
+    def step(i):
+        ids, labels = batches[i % len(batches)]
+        reducer.zero_grad()
+        with torch.autocast("cuda", dtype=amp, enabled=amp != torch.float32):
+            out = model(ids, labels=labels)
+        out.loss.backward()
+        reducer.finish()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return out.loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = step(i)
+    fence()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    prof = _lib.prof_read()
+    _lib.prof_reset()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        tokens = args.batch * args.seqlen * world * args.steps
+        E, N = 2 * args.d_model, SSM_CFG["d_state"]
+        s = 2 if args.dtype == "bf16" else 4
+        rows_tokens = 2 * args.batch * args.seqlen  # both strands go through every scan launch
+        alg = {"scan_fwd": (4 * E + 2 * N) * s * rows_tokens, "scan_bwd": (7 * E + 4 * N) * s * rows_tokens}
+        kinds = {}
+        for k in ("scan_fwd", "scan_bwd"):
+            ms, n = prof[k]
+            if n:
+                kinds[k] = {"launches": n, "avg_ms": ms / n, "achieved_GBps": alg[k] / (ms / n * 1e-3) / 1e9,
+                            "algorithmic_bytes_per_launch": alg[k], "total_ms": ms}
+        dom = max(kinds, key=lambda k: kinds[k]["total_ms"]) if kinds else None
+        roofline = None
+        if dom:
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": kinds[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": kinds[dom]["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": kinds[dom]["avg_ms"], "launches": kinds[dom]["launches"],
+                        "algorithmic_bytes_per_launch": kinds[dom]["algorithmic_bytes_per_launch"],
+                        "all": {k: {"avg_ms": v["avg_ms"], "achieved_GBps": v["achieved_GBps"],
+                                    "share_of_step": v["total_ms"] / (elapsed * 1e3)} for k, v in kinds.items()},
+                        "other_kernels_ms_per_step": {k: prof[k][0] / args.steps for k in prof
+                                                      if k not in kinds and prof[k][1]}}
+        cpu = None
+        if world == 1 and args.cpu_sample > 0:
+            try:
+                cpu = cpu_baseline(args.d_model, args.n_layer, args.cpu_sample)
+            except Exception as ex:  # the baseline is a reported number, never a reason to lose the GPU line
+                cpu = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+                       "sample": f"failed: {ex!r}"}
+        line = {
+            "metric": "DNA tokens/sec (whole node), hg38-style MLM pre-train step", "value": tokens / elapsed,
+            "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Caduceus-PS d_model={args.d_model} n_layer={args.n_layer} seqlen={args.seqlen} "
+                                   f"rcps=true MLM fwd+bwd+allreduce+AdamW, {args.batch} seq/GPU",
+                       "global_batch": args.batch * world, "seq_len": args.seqlen, "parallelism": f"dp{world}",
+                       "params": n_params, "final_loss": float(loss)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

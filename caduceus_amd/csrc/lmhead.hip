@@ -16,21 +16,31 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_fwd_kernel(cad_lm_head_
     const T* hid = (const T*)a.hidden;
     float loss_part = 0.f, cnt_part = 0.f;
     for (int64_t row = (int64_t)blockIdx.x * LM_WAVES + wave; row < a.rows; row += (int64_t)gridDim.x * LM_WAVES) {
-        float acc[LM_VMAX];
+        // Per-strand partial sums are kept apart and combined with ONE commutative add per lane, so that
+        // logits(x)[v] and logits(RC x)[comp v] (strand roles exchanged) are bit-identical, like the reference's
+        // `fwd_logits + rc_logits` (modeling_rcps.py:240-246).
+        float acc[LM_VMAX], acc1[LM_VMAX];
 #pragma unroll
-        for (int v = 0; v < LM_VMAX; ++v) acc[v] = 0.f;
-        for (int s = 0; s < a.n_strands; ++s) {
-            const T* h = hid + ((int64_t)s * a.rows + row) * D;
+        for (int v = 0; v < LM_VMAX; ++v) acc[v] = acc1[v] = 0.f;
+        {
+            const T* h = hid + row * D;
             for (int c = lane; c < D; c += 64) {
                 const float hv = to_f32(h[c]);
 #pragma unroll
-                for (int v = 0; v < LM_VMAX; ++v) {
-                    if (v < V) {
-                        const int64_t wr = (s == 1) ? a.comp[v] : v;
-                        acc[v] += hv * a.weight[wr * D + c];
-                    }
-                }
+                for (int v = 0; v < LM_VMAX; ++v)
+                    if (v < V) acc[v] += hv * a.weight[(int64_t)v * D + c];
             }
+        }
+        if (a.n_strands == 2) {
+            const T* h = hid + (a.rows + row) * D;
+            for (int c = lane; c < D; c += 64) {
+                const float hv = to_f32(h[c]);
+#pragma unroll
+                for (int v = 0; v < LM_VMAX; ++v)
+                    if (v < V) acc1[v] += hv * a.weight[a.comp[v] * D + c];
+            }
+#pragma unroll
+            for (int v = 0; v < LM_VMAX; ++v) acc[v] = acc[v] + acc1[v];
         }
 #pragma unroll
         for (int v = 0; v < LM_VMAX; ++v) {

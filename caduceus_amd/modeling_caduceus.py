@@ -55,16 +55,21 @@ class BiMambaWrapper(nn.Module):
             raise NotImplementedError(f"`{bidirectional_strategy}` strategy for bi-directionality is not implemented!")
         self.bidirectional = bidirectional
         self.bidirectional_strategy = bidirectional_strategy
+        self.bidirectional_weight_tie = bool(bidirectional and bidirectional_weight_tie)
         self.mamba_fwd = Mamba(d_model=d_model, **mamba_kwargs)
         if bidirectional:
             self.mamba_rev = Mamba(d_model=d_model, **mamba_kwargs)
-            if bidirectional_weight_tie:
-                self.mamba_rev.in_proj.weight = self.mamba_fwd.in_proj.weight
-                self.mamba_rev.in_proj.bias = self.mamba_fwd.in_proj.bias
-                self.mamba_rev.out_proj.weight = self.mamba_fwd.out_proj.weight
-                self.mamba_rev.out_proj.bias = self.mamba_fwd.out_proj.bias
+            self.retie()
         else:
             self.mamba_rev = None
+
+    def retie(self):
+        """Tie in and out projections (where most of param count lies), modeling_caduceus.py:114-118."""
+        if self.bidirectional_weight_tie:
+            self.mamba_rev.in_proj.weight = self.mamba_fwd.in_proj.weight
+            self.mamba_rev.in_proj.bias = self.mamba_fwd.in_proj.bias
+            self.mamba_rev.out_proj.weight = self.mamba_fwd.out_proj.weight
+            self.mamba_rev.out_proj.bias = self.mamba_fwd.out_proj.bias
 
     def forward_tframe(self, hn: torch.Tensor, strand_swap: bool) -> torch.Tensor:
         return engine.bimamba_tframe(hn, self.mamba_fwd, self.mamba_rev if self.bidirectional else None,
@@ -205,6 +210,27 @@ class CaduceusPreTrainedModel(PreTrainedModel):
                     with torch.no_grad():
                         p /= math.sqrt(n_residuals_per_layer * n_layer)
 
+    def _retie_shared(self, missing_keys=None):
+        """Re-establish module-level parameter sharing (BiMamba in/out projections) and publish the full alias map in
+        the form newer transformers releases use for (de)serialisation; tolerant of loaders that replaced parameters."""
+        for m in self.modules():
+            if isinstance(m, BiMambaWrapper) and m.bidirectional:
+                m.retie()
+        first, mapping = {}, {}
+        for name, p in self.named_parameters(remove_duplicate=False):
+            if id(p) in first:
+                mapping[name] = first[id(p)]
+            else:
+                first[id(p)] = name
+        self.all_tied_weights_keys = mapping
+        self._tied_weights_keys = dict(mapping)  # what save_pretrained consults for known duplicates
+        if missing_keys is not None:
+            for k in mapping:
+                missing_keys.discard(k)
+
+    def tie_weights(self, missing_keys=None, **kwargs):
+        self._retie_shared(missing_keys)
+
     @property
     def _return_dict_default(self):
         rd = getattr(self.config, "return_dict", None)
@@ -254,11 +280,8 @@ class CaduceusForMaskedLM(CaduceusPreTrainedModel):
         if config.rcps:
             self.lm_head = RCPSLMHead(complement_map=self.config.complement_map, vocab_size=self.config.vocab_size,
                                       true_dim=config.d_model, dtype=dtype)
-            self._tied_weights_keys = {
-                "lm_head.lm_head.weight": "caduceus.backbone.embeddings.word_embeddings.embedding.weight"}
         else:
             self.lm_head = nn.Linear(config.d_model, self.config.vocab_size, bias=False, **factory_kwargs)
-            self._tied_weights_keys = {"lm_head.weight": "caduceus.backbone.embeddings.word_embeddings.weight"}
         self.post_init()
 
     def get_input_embeddings(self):
@@ -277,15 +300,15 @@ class CaduceusForMaskedLM(CaduceusPreTrainedModel):
             raise NotImplementedError("Setting output embeddings for RCPS LM is not supported.")
         self.lm_head = new_embeddings
 
-    def tie_weights(self, *args, **kwargs):
-        """Tie weights, accounting for RCPS (modeling_caduceus.py:434-439).  Accepts (and ignores) the keyword
-        arguments newer transformers releases pass."""
-        if not getattr(self.config, "tie_word_embeddings", True):
-            return
-        if self.config.rcps:
-            self.lm_head.set_weight(self.get_input_embeddings().weight)
-        else:
-            self.lm_head.weight = self.get_input_embeddings().weight
+    def tie_weights(self, missing_keys=None, **kwargs):
+        """Tie weights, accounting for RCPS (modeling_caduceus.py:434-439).  Accepts the keyword arguments newer
+        transformers releases pass (`missing_keys`, `recompute_mapping`)."""
+        if getattr(self.config, "tie_word_embeddings", True):
+            if self.config.rcps:
+                self.lm_head.set_weight(self.get_input_embeddings().weight)
+            else:
+                self.lm_head.weight = self.get_input_embeddings().weight
+        self._retie_shared(missing_keys)
 
     def get_decoder(self):
         return self.caduceus

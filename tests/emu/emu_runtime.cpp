@@ -1,10 +1,37 @@
 // Fiber scheduler of the host emulator (see emu_runtime.h).  TEST INFRASTRUCTURE ONLY.
 #include "emu_runtime.h"
 
-#include <ucontext.h>
-
 #include <mutex>
 #include <vector>
+
+// Minimal x86-64 SysV context switch (callee-saved registers + stack pointer).  glibc's swapcontext() issues a
+// sigprocmask system call per switch, which made shuffle-heavy kernels ~50x slower to emulate.
+#if !defined(__x86_64__)
+#error "the host emulator's context switch is written for x86-64"
+#endif
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
 
 namespace emu {
 dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
@@ -13,30 +40,30 @@ namespace {
 constexpr size_t kStack = 256 * 1024;
 enum Wait { NONE = 0, BLOCK = 1, WAVE = 2 };
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;
     dim3 tid;
     bool done = false;
     int wait = NONE;
     unsigned wait_gen = 0;
-    int wave = 0, lane = 0;
+    int wave = 0, lane = 0, parity = 0;
 };
 struct WaveState {
     unsigned gen = 0;
     int arrived = 0, alive = 0;
-    uint64_t buf[64];
+    uint64_t buf[128];
 };
 std::vector<Fiber> fibers;
 std::vector<WaveState> waves;
 std::vector<char> stacks;
 std::vector<char> dynsmem;
-ucontext_t sched_ctx;
+void* sched_sp = nullptr;
 Fiber* cur = nullptr;
 unsigned block_gen = 0;
 int block_arrived = 0, block_alive = 0;
 const std::function<void()>* body_fn = nullptr;
 std::mutex launch_mu;
 
-void yield() { swapcontext(&cur->ctx, &sched_ctx); }
+void yield() { emu_switch(&cur->sp, sched_sp); }
 
 void trampoline() {
     (*body_fn)();
@@ -53,7 +80,8 @@ void trampoline() {
         w.arrived = 0;
         w.gen++;
     }
-    swapcontext(&cur->ctx, &sched_ctx);
+    emu_switch(&cur->sp, sched_sp);
+    std::abort();  // a finished fiber is never resumed
 }
 }  // namespace
 
@@ -84,6 +112,7 @@ void wave_sync() {
 
 uint64_t* wave_buf() { return waves[cur->wave].buf; }
 int lane_id() { return cur->lane; }
+int& lane_parity() { return cur->parity; }
 int wave_lanes() { return waves[cur->wave].alive; }
 char* dyn_smem() { return dynsmem.data(); }
 
@@ -117,11 +146,14 @@ void launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                     f.wave = t / 64;
                     f.lane = t % 64;
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = stacks.data() + (size_t)t * kStack;
-                    f.ctx.uc_stack.ss_size = kStack;
-                    f.ctx.uc_link = &sched_ctx;
-                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                    f.parity = 0;
+                    // initial frame: six callee-saved slots + return address = trampoline; the stack pointer at
+                    // trampoline entry must be 8 (mod 16) as after a `call`
+                    uintptr_t top = ((uintptr_t)(stacks.data() + (size_t)(t + 1) * kStack)) & ~(uintptr_t)15;
+                    void** frame = (void**)(top - 64);
+                    for (int q = 0; q < 6; ++q) frame[q] = nullptr;
+                    frame[6] = (void*)trampoline;
+                    f.sp = (void*)frame;
                 }
                 int remaining = nthreads;
                 while (remaining > 0) {
@@ -134,7 +166,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>
                         f.wait = NONE;
                         cur = &f;
                         g_threadIdx = f.tid;
-                        swapcontext(&sched_ctx, &f.ctx);
+                        emu_switch(&sched_sp, f.sp);
                         progressed = true;
                         if (f.done) remaining--;
                     }

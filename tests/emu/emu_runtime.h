@@ -26,7 +26,8 @@ extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body);
 void syncthreads();
 void wave_sync();
-uint64_t* wave_buf();  // 64 exchange slots of the calling fiber's wave
+uint64_t* wave_buf();  // 2 x 64 exchange slots of the calling fiber's wave (double buffered by parity)
+int& lane_parity();   // per-fiber shuffle parity
 int lane_id();
 int wave_lanes();
 char* dyn_smem();
@@ -54,11 +55,14 @@ inline T emu_exchange(T v, int src_lane) {
     static_assert(sizeof(T) <= 8, "shuffle payload");
     uint64_t raw = 0;
     std::memcpy(&raw, &v, sizeof(T));
-    uint64_t* buf = emu::wave_buf();
+    // one rendezvous per shuffle: consecutive shuffles alternate between two buffers, and a lane can never be two
+    // shuffles ahead of another lane of its wave because each shuffle contains a wave-wide rendezvous.
+    int& par = emu::lane_parity();
+    uint64_t* buf = emu::wave_buf() + 64 * par;
+    par ^= 1;
     buf[emu::lane_id()] = raw;
     emu::wave_sync();
     uint64_t r = buf[src_lane];
-    emu::wave_sync();
     T out;
     std::memcpy(&out, &r, sizeof(T));
     return out;

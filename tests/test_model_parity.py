@@ -1,0 +1,100 @@
+"""End-to-end parity of the HIP engine (flip-free t-frame) against the golden vectors generated from the reference's
+own classes, and against the CPU oracle, for every supported model variant.  Runs on the emulator (CPU) and on the GPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from caduceus_amd import CaduceusConfig, CaduceusForMaskedLM
+from conftest import MODEL_VARIANTS, load_golden_model
+from oracle import oracle_model as om
+
+FP32 = dict(rtol=6e-4, atol=2e-3)
+BF16 = dict(rtol=3e-2, atol=5e-2)
+
+
+def build_model(name, dev, dtype=torch.float32):
+    cfg, sd, rec = load_golden_model(name)
+    head, emb = (("lm_head.lm_head.weight", "caduceus.backbone.embeddings.word_embeddings.embedding.weight")
+                 if cfg["rcps"] else ("lm_head.weight", "caduceus.backbone.embeddings.word_embeddings.weight"))
+    config = CaduceusConfig(**cfg, tie_word_embeddings=bool(torch.equal(sd[head], sd[emb])), pad_token_id=4)
+    model = CaduceusForMaskedLM(config)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev).train(), cfg, sd, rec
+
+
+@pytest.mark.parametrize("name", MODEL_VARIANTS)
+def test_model_matches_reference_fp32(backend, name):
+    _, dev = backend
+    model, cfg, sd, rec = build_model(name, dev)
+    ids, labels = rec["input_ids"].to(dev), rec["labels"].to(dev)
+    out = model(ids, labels=labels)  # fused LM-head + CE kernel (ignore_index = pad_token_id = 4)
+    torch.testing.assert_close(out.logits.cpu(), rec["logits"], **FP32)
+    torch.testing.assert_close(out.loss.cpu(), rec["loss"], **FP32)
+    hidden = model.caduceus(ids).last_hidden_state
+    torch.testing.assert_close(hidden.cpu(), rec["hidden"], **FP32)
+    out.loss.backward()
+    named = model.state_dict(keep_vars=True)
+    checked = 0
+    for k, g in rec.items():
+        if not k.startswith("grad/"):
+            continue
+        got = named[k[5:]].grad
+        assert got is not None, k
+        scale = max(1.0, float(g.abs().max()))
+        torch.testing.assert_close(got.cpu(), g, rtol=6e-4, atol=2e-3 * scale, msg=lambda m, k=k: f"{k}: {m}")
+        checked += 1
+    assert checked > 10
+
+
+@pytest.mark.parametrize("name", ["ps_fused", "ps_unfused", "ph_fused"])
+def test_layer_trace_matches_reference(backend, name):
+    """Per-layer (hidden, residual) of the reference, through the module-level reference-frame API."""
+    _, dev = backend
+    model, cfg, sd, rec = build_model(name, dev)
+    bb = model.caduceus.backbone
+    hidden = bb.embeddings(rec["input_ids"].to(dev))
+    residual = None
+    for i, layer in enumerate(bb.layers):
+        hidden, residual = layer(hidden, residual)
+        torch.testing.assert_close(hidden.cpu(), rec[f"trace/{i}/hidden"], **FP32)
+        torch.testing.assert_close(residual.cpu(), rec[f"trace/{i}/residual"], **FP32)
+
+
+@pytest.mark.parametrize("name", ["ps_fused", "ph_fused", "ps_fused_res32_odd"])
+def test_model_bf16_autocast(backend, name):
+    """bf16 compute (autocast, fp32 master weights) against the fp32 reference vectors at the reference's bf16 tolerance."""
+    _, dev = backend
+    model, cfg, sd, rec = build_model(name, dev)
+    ids, labels = rec["input_ids"].to(dev), rec["labels"].to(dev)
+    with torch.autocast(dev.type, dtype=torch.bfloat16):
+        out = model(ids, labels=labels)
+    assert out.logits.dtype == torch.float32
+    # two+ layers of bf16 rounding on O(10) logits: judge the error in the relative L2 sense
+    rel = float((out.logits.cpu() - rec["logits"]).norm() / rec["logits"].norm())
+    assert rel < 3e-2, rel
+    assert abs(float(out.loss) - float(rec["loss"])) < 0.05 * max(1.0, float(rec["loss"]))
+    out.loss.backward()
+    g = model.state_dict(keep_vars=True)["caduceus.backbone.layers.0.mixer.submodule.mamba_fwd.x_proj.weight"
+                                         if cfg["rcps"] else "caduceus.backbone.layers.0.mixer.mamba_fwd.x_proj.weight"].grad
+    ref = rec["grad/caduceus.backbone.layers.0.mixer.submodule.mamba_fwd.x_proj.weight" if cfg["rcps"]
+              else "grad/caduceus.backbone.layers.0.mixer.mamba_fwd.x_proj.weight"]
+    cos = F.cosine_similarity(g.float().cpu().flatten(), ref.flatten(), dim=0)
+    assert cos > 0.99, float(cos)
+
+
+def test_inputs_embeds_and_hidden_states(backend):
+    _, dev = backend
+    model, cfg, sd, rec = build_model("ps_fused", dev)
+    ids = rec["input_ids"].to(dev)
+    emb = model.get_input_embeddings()(ids)  # (B, L, 2D) reference frame
+    ref_emb = om.rcps_embedding(sd["caduceus.backbone.embeddings.word_embeddings.embedding.weight"],
+                                sd["caduceus.backbone.embeddings.word_embeddings.complement_map"], rec["input_ids"])
+    assert torch.equal(emb.cpu(), ref_emb)
+    a = model(ids, output_hidden_states=True)
+    b = model(inputs_embeds=emb)
+    torch.testing.assert_close(a.logits, b.logits, rtol=0, atol=0)
+    assert len(a.hidden_states) == cfg["n_layer"] + 1  # reference quirk: final append only in the fused branch
+    torch.testing.assert_close(a.hidden_states[0].cpu(), ref_emb)
+    torch.testing.assert_close(a.hidden_states[-1].cpu(), rec["hidden"], **FP32)
+    tup = model(ids, labels=rec["labels"].to(dev), return_dict=False)
+    assert isinstance(tup, tuple) and tup[0].ndim == 0 and tup[1].shape == a.logits.shape

@@ -83,3 +83,24 @@ def test_reference_equivariance_vectors():
     torch.testing.assert_close(a, z["logits"], **TOL)
     assert torch.equal(a, torch.flip(b[..., comp], dims=[1]))
     assert torch.equal(om.rc_ids(z["input_ids"], comp), z["rc_input_ids"])
+
+
+@pytest.mark.parametrize("shape", ["1x64x64x16", "2x32x200x16", "1x16x37x8"])
+def test_c_oracle_scan_matches_third_party(shape):
+    """oracle/cad_oracle.c (used for large sizes and as the cpu_baseline port) against the same committed vectors."""
+    from oracle import oracle_ops
+    z = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, f"scan_op_{shape}.npz")).items()}
+    ins = {k: z[k].clone().requires_grad_(True) for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias")}
+    out = oracle_ops.selective_scan_c(ins["u"], ins["delta"], ins["A"], ins["B"], ins["C"], ins["D"], ins["z"],
+                                      ins["delta_bias"])
+    torch.testing.assert_close(out, z["out"], **TOL)
+    (out * z["dout"]).sum().backward()
+    for k in ins:
+        g = z["d" + k]
+        torch.testing.assert_close(ins[k].grad, g, rtol=2e-4, atol=5e-5 * max(1.0, float(g.abs().max())))
+
+
+def test_c_oracle_conv_matches_third_party():
+    from oracle import oracle_ops
+    z = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "conv_op.npz")).items()}
+    torch.testing.assert_close(oracle_ops.conv_fwd_c(z["x"], z["w"], z["b"]), z["out"], **TOL)
