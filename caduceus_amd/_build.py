@@ -20,15 +20,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = True) -> str:
-    """Cross-compiles every kernel for gfx950 (works without a GPU).  Objects are built in parallel."""
+def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = LIB) -> str:
+    """Cross-compiles every kernel for gfx950 (works without a GPU).  Objects are built in parallel.
+    `defines` / `out` build tuning variants (e.g. ("SC_S=8",)) next to the default library for A/B measurements."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "caduceus_hip.h")]
-    if not force and not _stale(LIB, deps):
-        return LIB
-    objdir = os.path.join(HERE, "build")
+    if not force and not _stale(out, deps):
+        return out
+    objdir = os.path.join(HERE, "build", os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+    flags += [f"-D{d}" for d in defines]
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -36,14 +38,14 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
                                                  stderr=subprocess.STDOUT)))
     objs = []
     for src, obj, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src}:\n{out.decode()}")
-        if verbose and out.strip():
-            print(out.decode())
+            raise RuntimeError(f"hipcc failed for {src}:\n{log.decode()}")
+        if verbose and log.strip():
+            print(log.decode())
         objs.append(obj)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
-    return LIB
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    return out
 
 
 if __name__ == "__main__":

@@ -13,7 +13,8 @@ import threading
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcaduceus_hip.so")
+# CADUCEUS_AMD_LIB selects another gfx950 build of the same sources (tuning variants); never a different backend
+LIB_PATH = os.environ.get("CADUCEUS_AMD_LIB") or os.path.join(HERE, "libcaduceus_hip.so")
 
 CAD_F32, CAD_BF16 = 0, 1
 PROF_KINDS = ("scan_fwd", "scan_bwd", "conv_fwd", "conv_bwd", "add_norm_fwd", "add_norm_bwd", "embed", "lm_head")
@@ -67,7 +68,8 @@ class ScanBwdArgs(C.Structure):
     _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
                 ("delta_bias", _p), ("dout", _p), ("chunk_state", _p), ("du", _p), ("ddelta", _p), ("dz", _p),
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
-                ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
+                ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
+                ("n_partials", _i)]
 
 
 class LmHeadArgs(C.Structure):
@@ -91,6 +93,9 @@ SYMBOLS = {
     "cad_scan_chunk_len": (_i64, []),
     "cad_scan_state_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_scan_bwd": (_i, [C.POINTER(ScanBwdArgs), _p]),
+    "cad_scan_fwd_multi": (_i, [C.POINTER(ScanArgs), _i, _p]),
+    "cad_scan_bwd_multi": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
+    "cad_reduce_partials": (_i, [_p, _i, _i64, _p, _i, _p]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_prof_enable": (_i, [_i]),
     "cad_prof_reset": (_i, []),

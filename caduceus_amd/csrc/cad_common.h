@@ -117,6 +117,80 @@ __device__ __forceinline__ float cad_softplus(float x) {
 }
 __device__ __forceinline__ float cad_sigmoid(float x) { return cad_rcp(1.0f + cad_exp(-x)); }
 
+// ---- cross-lane primitives (DPP on gfx950; emulated through the fiber exchange in the test build) -----------------
+// Each returns, per lane, the value of `v` in the source lane selected by the pattern, or `old` where the pattern has
+// no source for this lane -- exactly v_mov_b32_dpp with bound_ctrl:0.  Passing the identity element as `old` lets a
+// scan step run unconditionally on all lanes.
+#ifdef CAD_EMU
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float old, float v) {
+    const int lane = emu::lane_id();
+    const bool ok = (lane & 15) >= N;
+    const float r = emu_exchange(v, ok ? lane - N : lane);
+    return ok ? r : old;
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float old, float v) {
+    const int lane = emu::lane_id();
+    const bool ok = (lane & 15) + N < 16;
+    const float r = emu_exchange(v, ok ? lane + N : lane);
+    return ok ? r : old;
+}
+__device__ __forceinline__ float dpp_row_bcast15(float old, float v) {  // rows 1 and 3 <- lane 15 of the previous row
+    const int lane = emu::lane_id();
+    const bool ok = ((lane >> 4) & 1) == 1;
+    const float r = emu_exchange(v, ok ? (lane & ~15) - 1 : lane);
+    return ok ? r : old;
+}
+__device__ __forceinline__ float dpp_row_bcast31(float old, float v) {  // rows 2 and 3 <- lane 31
+    const int lane = emu::lane_id();
+    const bool ok = lane >= 32;
+    const float r = emu_exchange(v, ok ? 31 : lane);
+    return ok ? r : old;
+}
+__device__ __forceinline__ float dpp_wave_shr1(float old, float v) {
+    const int lane = emu::lane_id();
+    const float r = emu_exchange(v, lane >= 1 ? lane - 1 : lane);
+    return lane >= 1 ? r : old;
+}
+__device__ __forceinline__ float dpp_wave_shl1(float old, float v) {
+    const int lane = emu::lane_id();
+    const float r = emu_exchange(v, lane < 63 ? lane + 1 : lane);
+    return lane < 63 ? r : old;
+}
+__device__ __forceinline__ float cad_readlane(float v, int l) { return emu_exchange(v, l); }
+__device__ __forceinline__ int cad_xcc_id() { return (int)((blockIdx.x * 5 + blockIdx.y * 3 + blockIdx.z) & 7); }
+__device__ __forceinline__ void cad_atomic_add_l2(float* p, float v) { *p += v; }
+#else
+#define CAD_DPP(old, v, ctrl, rmask)                                                                          \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)),              \
+                                                          __builtin_bit_cast(int, (float)(v)), (ctrl), (rmask), 0xf, false))
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float old, float v) {
+    return CAD_DPP(old, v, 0x110 + N, 0xf);
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float old, float v) {
+    return CAD_DPP(old, v, 0x100 + N, 0xf);
+}
+__device__ __forceinline__ float dpp_row_bcast15(float old, float v) { return CAD_DPP(old, v, 0x142, 0xa); }
+__device__ __forceinline__ float dpp_row_bcast31(float old, float v) { return CAD_DPP(old, v, 0x143, 0xc); }
+__device__ __forceinline__ float dpp_wave_shr1(float old, float v) { return CAD_DPP(old, v, 0x138, 0xf); }
+__device__ __forceinline__ float dpp_wave_shl1(float old, float v) { return CAD_DPP(old, v, 0x130, 0xf); }
+__device__ __forceinline__ float cad_readlane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// XCC (XCD) this wave runs on: HW_REG_XCC_ID (id 20), bits [3:0].  Used ONLY to pick which of 8 partial-sum
+// buffers receives this workgroup's L2-scope atomics: all CUs reporting the same id share one L2, so every value
+// in 0..7 is correct; the dispatcher's placement only affects speed.
+__device__ __forceinline__ int cad_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7); }
+// fp32 atomic add resolved in the XCD's L2 (no sc1 / fabric round trip).  Only valid on buffers that are private to
+// one XCD for the duration of the kernel (see cad_xcc_id); visible to later kernels after the end-of-kernel writeback.
+__device__ __forceinline__ void cad_atomic_add_l2(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#endif
+
 // ---- direction / index maps ----------------------------------------------------------------------------------
 // logical position p in [0, L) of a row <-> physical index along L
 __device__ __forceinline__ int64_t cad_phys(int64_t p, int64_t L, int rev) { return rev ? (L - 1 - p) : p; }

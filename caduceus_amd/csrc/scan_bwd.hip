@@ -1,24 +1,32 @@
-// Selective SSM scan, backward (include/caduceus_hip.h, cad_scan_bwd).  See scan_common.h for the decomposition.
+// Selective SSM scan, backward (include/caduceus_hip.h, cad_scan_bwd / cad_scan_bwd_multi).
+// See scan_common.h for the decomposition.
 //
 // Per chunk (processed from the logical END of the row to its start, because the state gradient flows backwards)
 // and per state pair:
-//   1. recompute h over the chunk from the chunk-start state saved by the forward (serial + wave scan, as fwd);
+//   1. recompute h over the chunk from the chunk-start state saved by the forward (serial + DPP wave scan);
 //   2. reverse scan of  G_i = a_i * (c_i + G_{i+1}),  c_i = C_i * dy_i   (G_i = gradient flowing into h_{i-1});
 //      g_i = c_i + G_{i+1} is dL/dh_i;
 //   3. per item:  d(dt) += g*h_{i-1}*a*A + u*<g,B>,  dA += g*h_{i-1}*a*dt,  du += dt*<g,B>,
-//                 dB_i = g*dt*u,  dC_i = dy*h_i  -- the last two are summed over the SC_W channels of the workgroup
-//                 in LDS (ds_add_f32) and then added to the fp32 global buffers with one atomic per element.
+//                 dB_i = g*dt*u,  dC_i = dy*h_i.
+// dB / dC must be summed over all E channels.  The SC_W channels of a workgroup are summed in LDS (ds_add_f32 into a
+// double-buffered tile), then the tile is added -- token-contiguous, coalesced -- to one of `n_partials` global fp32
+// buffers with fp32 atomics.  With n_partials == 8 the buffer is chosen by the XCD the workgroup runs on and the
+// atomics resolve in that XCD's L2 (no fabric round trip); cad_reduce_partials folds the 8 buffers afterwards.
 #include "scan_common.h"
 
 namespace {
 
+struct ScanBwdSets {
+    cad_scan_bwd_args s[SC_MAXSETS];
+};
+
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum1(v[0]), wave_sum1(v[1])); }
 
 template <typename T>
-__global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a) {
-    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE] inputs, then [dB,dC][SC_TILE] accumulators
-    float* accB = smem + 4 * SC_TILE;
-    float* accC = accB + SC_TILE;
+__global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
+    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE] inputs, then [2 buffers][dB,dC][SC_TILE] accumulators
+    const cad_scan_bwd_args& a = sets.s[blockIdx.z];
+    float* acc = smem + 4 * SC_TILE;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t sb = blockIdx.y;
@@ -39,33 +47,57 @@ __global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
     const bool vec_ok =
-        ((L * sizeof(T)) % 16) == 0 && (((uintptr_t)a.u | (uintptr_t)a.delta | (uintptr_t)a.z | (uintptr_t)a.dout |
-                                         (uintptr_t)a.du | (uintptr_t)a.ddelta | (uintptr_t)a.dz) %
-                                        16) == 0;
+        ((L * sizeof(T)) % 16) == 0 &&
+        (((uintptr_t)a.u | (uintptr_t)a.delta | (uintptr_t)a.z | (uintptr_t)a.dout | (uintptr_t)a.du |
+          (uintptr_t)a.ddelta | (uintptr_t)a.dz | (uintptr_t)a.Bm | (uintptr_t)a.Cm) % 16) == 0;
     const float Dv = a.D ? a.D[e] : 0.f;
     const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const float keep = act ? 1.f : 0.f;  // padding waves (E % SC_W != 0) contribute nothing
+    const int64_t part_stride = (int64_t)N * SB * L;
+    const bool l2_atomics = a.n_partials > 1;
+    const int part = l2_atomics ? (cad_xcc_id() % a.n_partials) : 0;
+    float* dBg = a.dB + (int64_t)part * part_stride;
+    float* dCg = a.dC + (int64_t)part * part_stride;
 
-    for (int i = threadIdx.x; i < 2 * SC_TILE; i += blockDim.x) accB[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * SC_TILE; i += blockDim.x) acc[i] = 0.f;
+
+    StageRegs<T> st;
+    ScVec<T> u_raw, d_raw, g_raw, z_raw;
+    {
+        const int64_t base = (nchunks - 1) * SC_CHUNK;
+        sc_stage_load(st, Bm, Cm, 0, N, SB, sb, base, L, rev, vec_ok);
+        sc_load_raw(u_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, u_raw);
+        sc_load_raw(d_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, d_raw);
+        sc_load_raw(g_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, g_raw);
+        if (z_row) sc_load_raw(z_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, z_raw);
+        sc_stage_store(st, smem, rev);
+    }
     __syncthreads();
 
     f32x2 carryG = f2(0.f);  // lane np: G flowing out of the later chunk into this one, for pair np
     f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
     float dDacc = 0.f, dbacc = 0.f;
+    int tix = 0;
 
     for (int64_t c = nchunks - 1; c >= 0; --c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float uu[SC_S], dt[SC_S], dy[SC_S], ddt[SC_S], ddu[SC_S], y[SC_S];
-        sc_load(u_row, p0, L, rev, vec_ok, uu);
-        sc_load(d_row, p0, L, rev, vec_ok, dt);
-        sc_load(g_row, p0, L, rev, vec_ok, dy);
+        sc_unpack(u_raw, rev, uu);
+        sc_unpack(d_raw, rev, dt);
+        sc_unpack(g_raw, rev, dy);
         if (z_row) {
             float zz[SC_S];
-            sc_load(z_row, p0, L, rev, vec_ok, zz);
+            sc_unpack(z_raw, rev, zz);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
+        }
+        if (c > 0) {  // prefetch the item vectors of the next (earlier) chunk
+            sc_load_raw(u_row, p0 - SC_CHUNK, L, rev, vec_ok, u_raw);
+            sc_load_raw(d_row, p0 - SC_CHUNK, L, rev, vec_ok, d_raw);
+            sc_load_raw(g_row, p0 - SC_CHUNK, L, rev, vec_ok, g_raw);
+            if (z_row) sc_load_raw(z_row, p0 - SC_CHUNK, L, rev, vec_ok, z_raw);
         }
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
@@ -77,20 +109,23 @@ __global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a
             ddu[i] = dy[i] * Dv;
             dDacc += dy[i] * uu[i];
         }
-        sc_stage_bc(smem, smem + SC_TILE, Bm, Cm, 0, N, SB, sb, base, L, rev);
-        __syncthreads();
-        for (int np = 0; np < NP; ++np) {
-            const int buf = np & 1;
-            if (np + 1 < NP)
-                sc_stage_bc(smem + (buf ^ 1) * 2 * SC_TILE, smem + (buf ^ 1) * 2 * SC_TILE + SC_TILE, Bm, Cm,
-                            2 * (np + 1), N, SB, sb, base, L, rev);
+        for (int np = 0; np < NP; ++np, ++tix) {
+            const int buf = tix & 1;
+            const bool more = (np + 1 < NP) || (c > 0);
+            if (more) {
+                const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
+                const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
+                sc_stage_load(st, Bm, Cm, nn, N, SB, sb, nb, L, rev, vec_ok);
+            }
             const float* tB = smem + buf * 2 * SC_TILE + lane * SC_ROW;
             const float* tC = tB + SC_TILE;
+            float* aB = acc + buf * 2 * SC_TILE + lane * SC_ROW;
+            float* aC = aB + SC_TILE;
             const int n0 = 2 * np;
             const f32x2 Av = f2(a.A[e * N + n0], (n0 + 1 < N) ? a.A[e * N + n0 + 1] : 0.f);
             const f32x2 A2 = Av * f2(CAD_LOG2E);
-            const float* st = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + np) * 2;
-            const f32x2 hin = f2(st[0], st[1]);
+            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + np) * 2;
+            const f32x2 hin = f2(stp[0], stp[1]);
             // 1. forward recompute: serial totals, wave scan, then the true h_i
             f32x2 av[SC_S], hs[SC_S];
             f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
@@ -102,19 +137,9 @@ __global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a
                 acc_a = acc_a * av[i];
             }
             f32x2 PA = acc_a, PH = acc_h;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const f32x2 ua = shfl_up2(PA, d), uh = shfl_up2(PH, d);
-                if (lane >= d) {
-                    PH = PA * uh + PH;
-                    PA = PA * ua;
-                }
-            }
-            f32x2 ea = shfl_up2(PA, 1), eh = shfl_up2(PH, 1);
-            if (lane == 0) {
-                ea = f2(1.f);
-                eh = f2(0.f);
-            }
+            wave_scan_fwd(PA, PH);
+            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
+            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
             const f32x2 h0 = ea * hin + eh;  // state entering this lane's segment
             {
                 f32x2 h = h0;
@@ -130,27 +155,15 @@ __global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a
 #pragma unroll
             for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (ld2(tC + 2 * i) * f2(dy[i]) + RG);
             f32x2 QA = acc_a, QG = RG;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const f32x2 ua = shfl_down2(QA, d), ug = shfl_down2(QG, d);
-                if (lane + d < 64) {
-                    QG = QA * ug + QG;
-                    QA = QA * ua;
-                }
-            }
-            f32x2 fa = shfl_down2(QA, 1), fg = shfl_down2(QG, 1);
-            if (lane == 63) {
-                fa = f2(1.f);
-                fg = f2(0.f);
-            }
-            const f32x2 gin = shfl2(carryG, np);
+            wave_scan_rev(QA, QG, lane);
+            const f32x2 fa = f2(dpp_wave_shl1(1.f, QA[0]), dpp_wave_shl1(1.f, QA[1]));
+            const f32x2 fg = f2(dpp_wave_shl1(0.f, QG[0]), dpp_wave_shl1(0.f, QG[1]));
+            const f32x2 gin = readlane2(carryG, np);
             f32x2 G = fa * gin + fg;  // G_{i+1} for this lane's last item
-            const f32x2 newc = shfl2(QA * gin + QG, 0);
+            const f32x2 newc = readlane2(QA * gin + QG, 0);
             if (lane == np) carryG = newc;
             // 3. gradients
             f32x2 dAp = f2(0.f);
-            float* aB = accB + lane * SC_ROW;
-            float* aC = accC + lane * SC_ROW;
 #pragma unroll
             for (int i = SC_S - 1; i >= 0; --i) {
                 const f32x2 Bv = ld2(tB + 2 * i);
@@ -171,24 +184,37 @@ __global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a
             }
             dAp = wave_sum2(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
-            __syncthreads();  // all channels of the workgroup have added their dB/dC; tile buf is free again
-            // flush the channel-summed dB / dC tile of this pair to global (fp32 atomics), then clear it
-            for (int idx = threadIdx.x; idx < 2 * SC_CHUNK; idx += blockDim.x) {
-                const int s = idx / SC_CHUNK;
-                const int tok = idx - s * SC_CHUNK;
-                const int64_t p = base + tok;
-                const int o = (tok / SC_S) * SC_ROW + (tok % SC_S) * 2 + s;
-                if (p < L && n0 + s < N) {
-                    const int64_t off = ((int64_t)(n0 + s) * SB + sb) * L + cad_phys(p, L, rev);
-                    atomicAdd(a.dB + off, accB[o]);
-                    atomicAdd(a.dC + off, accC[o]);
+            if (more) sc_stage_store(st, smem + (buf ^ 1) * 2 * SC_TILE, rev);
+            __syncthreads();  // every channel has added its dB/dC; the prefetched B/C tile is visible
+            // flush the channel-summed dB / dC tile of this pair (token-contiguous per thread), then clear it; the
+            // other accumulator buffer is the one the next pair adds into, so no second barrier is needed
+            {
+                const int t = threadIdx.x;
+                float* tile = acc + buf * 2 * SC_TILE + (t >> 7) * SC_TILE;
+                float* gdst = (t >> 7) ? dCg : dBg;
+                const int tok = (t & 127) * SC_SV;
+                float* src = tile + (tok / SC_S) * SC_ROW + (tok % SC_S) * 2;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (n0 + s < N) {
+                        float* grow = gdst + ((int64_t)(n0 + s) * SB + sb) * L;
+#pragma unroll
+                        for (int j = 0; j < SC_SV; ++j) {
+                            const int64_t p = base + tok + j;
+                            if (p < L) {
+                                if (l2_atomics)
+                                    cad_atomic_add_l2(grow + cad_phys(p, L, rev), src[2 * j + s]);
+                                else
+                                    atomicAdd(grow + cad_phys(p, L, rev), src[2 * j + s]);
+                            }
+                        }
+                    }
                 }
-                accB[o] = 0.f;
-                accC[o] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2 * SC_SV; ++j) src[j] = 0.f;
             }
-            __syncthreads();
         }
-        // per-item outputs of this chunk
+        // per-item outputs of this chunk (delta / z / dout are re-read: still L2-resident, keeps 48 VGPRs free)
         float dl[SC_S];
         sc_load(d_row, p0, L, rev, vec_ok, dl);
 #pragma unroll
@@ -215,12 +241,10 @@ __global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a
         }
     }
     // per-channel parameter gradients
-    if (act) {
-        if (lane < NP) {
-            const int n0 = 2 * lane;
-            atomicAdd(a.dA + e * N + n0, dAacc[0]);
-            if (n0 + 1 < N) atomicAdd(a.dA + e * N + n0 + 1, dAacc[1]);
-        }
+    if (act && lane < NP) {
+        const int n0 = 2 * lane;
+        atomicAdd(a.dA + e * N + n0, dAacc[0]);
+        if (n0 + 1 < N) atomicAdd(a.dA + e * N + n0 + 1, dAacc[1]);
     }
     dDacc = wave_sum1(dDacc);
     dbacc = wave_sum1(dbacc);
@@ -230,21 +254,59 @@ __global__ __launch_bounds__(64 * SC_W) void scan_bwd_kernel(cad_scan_bwd_args a
     }
 }
 
+// dst[i] = sum_k src[k * n + i]  (fp32 partial buffers -> dtype)
+template <typename T>
+__global__ void reduce_partials_kernel(const float* src, int nparts, int64_t n, T* dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float s = 0.f;
+        for (int k = 0; k < nparts; ++k) s += src[(int64_t)k * n + i];
+        dst[i] = from_f32<T>(s);
+    }
+}
+
 }  // namespace
 
-extern "C" int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream) {
-    CAD_CHECK_ARG(a && a->u && a->delta && a->A && a->Bm && a->Cm && a->dout && a->chunk_state);
-    CAD_CHECK_ARG(a->du && a->ddelta && a->dA && a->dB && a->dC);
-    CAD_CHECK_ARG((a->z == nullptr) == (a->dz == nullptr));
-    CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
-    CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
+extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream) {
+    CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= SC_MAXSETS);
+    ScanBwdSets ks;
+    for (int i = 0; i < nsets; ++i) {
+        const cad_scan_bwd_args* a = &sets[i];
+        CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && a->dout && a->chunk_state);
+        CAD_CHECK_ARG(a->du && a->ddelta && a->dA && a->dB && a->dC);
+        CAD_CHECK_ARG((a->z == nullptr) == (a->dz == nullptr));
+        CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
+        CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
+        CAD_CHECK_ARG(a->n_partials == 1 || a->n_partials == 8);
+        CAD_CHECK_ARG(a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L && a->N == sets[0].N &&
+                      a->dtype == sets[0].dtype);
+        ks.s[i] = *a;
+    }
+    for (int i = nsets; i < SC_MAXSETS; ++i) ks.s[i] = sets[0];
+    const cad_scan_bwd_args* a = &sets[0];
     CadProfScope prof(1, stream);
-    dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB), block(64 * SC_W);
-    const size_t shmem = (size_t)6 * SC_TILE * sizeof(float);
+    dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
+    const size_t shmem = (size_t)8 * SC_TILE * sizeof(float);
     if (a->dtype == CAD_F32)
-        CAD_LAUNCH((scan_bwd_kernel<float>), grid, block, shmem, stream, *a);
+        CAD_LAUNCH((scan_bwd_kernel<float>), grid, block, shmem, stream, ks);
     else if (a->dtype == CAD_BF16)
-        CAD_LAUNCH((scan_bwd_kernel<bf16_t>), grid, block, shmem, stream, *a);
+        CAD_LAUNCH((scan_bwd_kernel<bf16_t>), grid, block, shmem, stream, ks);
+    else
+        return CAD_ERR_UNSUPPORTED;
+    return cad_after_launch();
+}
+
+extern "C" int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream) { return cad_scan_bwd_multi(a, 1, stream); }
+
+extern "C" int cad_reduce_partials(const float* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream) {
+    CAD_CHECK_ARG(src && dst && n_partials >= 1 && n > 0);
+    int64_t nb = (n + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    dim3 grid((unsigned)nb), block(256);
+    if (dst_dtype == CAD_F32)
+        CAD_LAUNCH((reduce_partials_kernel<float>), grid, block, 0, stream, src, n_partials, n, (float*)dst);
+    else if (dst_dtype == CAD_BF16)
+        CAD_LAUNCH((reduce_partials_kernel<bf16_t>), grid, block, 0, stream, src, n_partials, n, (bf16_t*)dst);
     else
         return CAD_ERR_UNSUPPORTED;
     return cad_after_launch();

@@ -5,20 +5,30 @@
 //     = 1024 logical positions; lane j owns SC_S consecutive positions, so every HBM access of u/delta/z/out is
 //     a contiguous, fully coalesced 2 KB (bf16) segment along L;
 //   * the recurrence over L is split into (i) an in-register serial scan over a lane's SC_S items, (ii) a
-//     Kogge-Stone scan of the affine maps (a, b) across the 64 lanes (6 shuffle steps) and (iii) a carry to the
-//     next chunk; the N states are processed two at a time (float2 -> v_pk_mul/fma_f32);
+//     Kogge-Stone scan of the affine maps (a, b) across the 64 lanes -- DPP row shifts inside 16-lane rows,
+//     row_bcast15/31 across rows, no LDS -- and (iii) a carry to the next chunk; the N states are processed two at a
+//     time (float2 -> v_pk_mul/fma_f32);
 //   * the SC_W waves (channels) of a workgroup share the B/C tiles of the current state pair through LDS
-//     (double buffered, padded rows -> conflict-free ds_read_b64/b128).
+//     (double buffered, prefetched one pair ahead through registers, padded rows -> conflict-free ds_read_b64/b128);
+//   * up to two parameter sets (mamba_fwd / mamba_rev of a BiMamba layer) run in ONE launch (grid.z) so that a CU
+//     holds two independent waves per SIMD even at batch 1.
 // A right-to-left row uses the same code with physical index L-1-p: an exact mirror of the left-to-right order.
 #pragma once
 #include "cad_common.h"
 
-#define SC_S 16                 // items per lane
+#ifndef SC_S
+#define SC_S 16                 // items per lane (8 or 16)
+#endif
+#ifndef SC_OCC
+#define SC_OCC 2                // register budget: waves per SIMD the kernels are compiled for
+#endif
 #define SC_W 4                  // waves (= channels) per workgroup
 #define SC_CHUNK (64 * SC_S)    // logical positions per chunk step
 #define SC_ROW (2 * SC_S + 4)   // floats per lane row of a B/C tile (16 x float2 + 16 B pad: stride 144 B)
 #define SC_TILE (64 * SC_ROW)   // floats per tile
-#define SC_NMAX 64              // max d_state (pairs are indexed by lane: N/2 <= 64 would allow 128; keep 64)
+#define SC_NMAX 64              // max d_state
+#define SC_MAXSETS 2
+#define SC_SV (SC_CHUNK / 128)   // tokens per staging thread (256 threads = 2 tensors x 128 threads x SC_SV tokens)
 
 __device__ __forceinline__ f32x2 f2(float a) {
     f32x2 r = {a, a};
@@ -32,48 +42,100 @@ __device__ __forceinline__ f32x2 ld2(const float* p) {
     f32x2 r = {p[0], p[1]};
     return r;
 }
-__device__ __forceinline__ f32x2 shfl_up2(f32x2 v, int d) { return f2(__shfl_up(v[0], d), __shfl_up(v[1], d)); }
-__device__ __forceinline__ f32x2 shfl_down2(f32x2 v, int d) { return f2(__shfl_down(v[0], d), __shfl_down(v[1], d)); }
-__device__ __forceinline__ f32x2 shfl2(f32x2 v, int src) { return f2(__shfl(v[0], src), __shfl(v[1], src)); }
 __device__ __forceinline__ f32x2 exp2_2(f32x2 v) { return f2(cad_exp2(v[0]), cad_exp2(v[1])); }
 __device__ __forceinline__ float dot2(f32x2 a, f32x2 b) { return a[0] * b[0] + a[1] * b[1]; }
+__device__ __forceinline__ f32x2 readlane2(f32x2 v, int l) { return f2(cad_readlane(v[0], l), cad_readlane(v[1], l)); }
 __device__ __forceinline__ float wave_sum1(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
 
-// SC_S logical positions [p0, p0+S) of a row -> out[] (zeros outside [0, L))
+// One Kogge-Stone step of the affine-map scan: (A, H) <- (A, H) o (ua, uh) where (ua, uh) is the partner's map
+// (identity where the DPP pattern has no source):  x -> A * (ua * x + uh) + H.
+#define SC_COMBINE(A, H, UA0, UA1, UH0, UH1) \
+    do {                                     \
+        const f32x2 ua_ = f2(UA0, UA1);      \
+        const f32x2 uh_ = f2(UH0, UH1);      \
+        H = A * uh_ + H;                     \
+        A = A * ua_;                         \
+    } while (0)
+
+// Inclusive scan in lane order (lane 0 first).  On return (A, H) of lane j is the composition of lanes 0..j.
+__device__ __forceinline__ void wave_scan_fwd(f32x2& A, f32x2& H) {
+    SC_COMBINE(A, H, dpp_row_shr<1>(1.f, A[0]), dpp_row_shr<1>(1.f, A[1]), dpp_row_shr<1>(0.f, H[0]), dpp_row_shr<1>(0.f, H[1]));
+    SC_COMBINE(A, H, dpp_row_shr<2>(1.f, A[0]), dpp_row_shr<2>(1.f, A[1]), dpp_row_shr<2>(0.f, H[0]), dpp_row_shr<2>(0.f, H[1]));
+    SC_COMBINE(A, H, dpp_row_shr<4>(1.f, A[0]), dpp_row_shr<4>(1.f, A[1]), dpp_row_shr<4>(0.f, H[0]), dpp_row_shr<4>(0.f, H[1]));
+    SC_COMBINE(A, H, dpp_row_shr<8>(1.f, A[0]), dpp_row_shr<8>(1.f, A[1]), dpp_row_shr<8>(0.f, H[0]), dpp_row_shr<8>(0.f, H[1]));
+    SC_COMBINE(A, H, dpp_row_bcast15(1.f, A[0]), dpp_row_bcast15(1.f, A[1]), dpp_row_bcast15(0.f, H[0]), dpp_row_bcast15(0.f, H[1]));
+    SC_COMBINE(A, H, dpp_row_bcast31(1.f, A[0]), dpp_row_bcast31(1.f, A[1]), dpp_row_bcast31(0.f, H[0]), dpp_row_bcast31(0.f, H[1]));
+}
+
+// Inclusive scan in REVERSE lane order (lane 63 first): (A, G) of lane j is the composition of lanes 63..j.
+// Row-local steps use DPP row_shl; the two cross-row steps have no DPP broadcast in this direction and go through
+// ds_bpermute (__shfl) / readlane.
+__device__ __forceinline__ void wave_scan_rev(f32x2& A, f32x2& G, int lane) {
+    SC_COMBINE(A, G, dpp_row_shl<1>(1.f, A[0]), dpp_row_shl<1>(1.f, A[1]), dpp_row_shl<1>(0.f, G[0]), dpp_row_shl<1>(0.f, G[1]));
+    SC_COMBINE(A, G, dpp_row_shl<2>(1.f, A[0]), dpp_row_shl<2>(1.f, A[1]), dpp_row_shl<2>(0.f, G[0]), dpp_row_shl<2>(0.f, G[1]));
+    SC_COMBINE(A, G, dpp_row_shl<4>(1.f, A[0]), dpp_row_shl<4>(1.f, A[1]), dpp_row_shl<4>(0.f, G[0]), dpp_row_shl<4>(0.f, G[1]));
+    SC_COMBINE(A, G, dpp_row_shl<8>(1.f, A[0]), dpp_row_shl<8>(1.f, A[1]), dpp_row_shl<8>(0.f, G[0]), dpp_row_shl<8>(0.f, G[1]));
+    // after the row-local steps the FIRST lane of every row holds its whole row; fold the later rows in
+    {   // rows 0 and 2 <- total of the next row
+        const int src = (((lane >> 4) + 1) << 4) & 63;
+        const float a0 = __shfl(A[0], src), a1 = __shfl(A[1], src), g0 = __shfl(G[0], src), g1 = __shfl(G[1], src);
+        const bool ok = ((lane >> 4) & 1) == 0;
+        SC_COMBINE(A, G, ok ? a0 : 1.f, ok ? a1 : 1.f, ok ? g0 : 0.f, ok ? g1 : 0.f);
+    }
+    {   // rows 0 and 1 <- total of rows 2..3 (now at lane 32)
+        const float a0 = __shfl(A[0], 32), a1 = __shfl(A[1], 32), g0 = __shfl(G[0], 32), g1 = __shfl(G[1], 32);
+        const bool ok = lane < 32;
+        SC_COMBINE(A, G, ok ? a0 : 1.f, ok ? a1 : 1.f, ok ? g0 : 0.f, ok ? g1 : 0.f);
+    }
+}
+
+// ---- per-lane item vectors -------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void sc_load(const T* row, int64_t p0, int64_t L, int rev, bool vec_ok, float* out) {
+struct __attribute__((aligned(16))) ScVec {
+    T v[SC_S];
+};
+
+// raw (un-converted) load of SC_S logical positions [p0, p0+S); tail / unaligned rows fall back to scalar loads.
+template <typename T>
+__device__ __forceinline__ void sc_load_raw(const T* row, int64_t p0, int64_t L, int rev, bool vec_ok, ScVec<T>& out) {
     if (vec_ok && p0 + SC_S <= L) {
         const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
-        typedef struct __attribute__((aligned(16))) {
-            T v[SC_S];
-        } vec_t;
-        const vec_t tmp = *(const vec_t*)(row + l0);
-#pragma unroll
-        for (int j = 0; j < SC_S; ++j) out[j] = to_f32(tmp.v[rev ? (SC_S - 1 - j) : j]);
+        out = *(const ScVec<T>*)(row + l0);
     } else {
 #pragma unroll
         for (int j = 0; j < SC_S; ++j) {
             const int64_t p = p0 + j;
-            out[j] = (p < L) ? to_f32(row[cad_phys(p, L, rev)]) : 0.f;
+            const int k = rev ? (SC_S - 1 - j) : j;  // keep the physical (memory-order) register layout of the fast path
+            if (p < L)
+                out.v[k] = row[cad_phys(p, L, rev)];
+            else
+                out.v[k] = from_f32<T>(0.f);
         }
     }
 }
-
+template <typename T>
+__device__ __forceinline__ void sc_unpack(const ScVec<T>& raw, int rev, float* out) {
+#pragma unroll
+    for (int j = 0; j < SC_S; ++j) out[j] = to_f32(raw.v[rev ? (SC_S - 1 - j) : j]);
+}
+template <typename T>
+__device__ __forceinline__ void sc_load(const T* row, int64_t p0, int64_t L, int rev, bool vec_ok, float* out) {
+    ScVec<T> raw;
+    sc_load_raw(row, p0, L, rev, vec_ok, raw);
+    sc_unpack(raw, rev, out);
+}
 template <typename T>
 __device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev, bool vec_ok, const float* v) {
     if (vec_ok && p0 + SC_S <= L) {
         const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
-        typedef struct __attribute__((aligned(16))) {
-            T v[SC_S];
-        } vec_t;
-        vec_t tmp;
+        ScVec<T> tmp;
 #pragma unroll
         for (int j = 0; j < SC_S; ++j) tmp.v[rev ? (SC_S - 1 - j) : j] = from_f32<T>(v[j]);
-        *(vec_t*)(row + l0) = tmp;
+        *(ScVec<T>*)(row + l0) = tmp;
     } else {
 #pragma unroll
         for (int j = 0; j < SC_S; ++j) {
@@ -83,23 +145,56 @@ __device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev,
     }
 }
 
-// Stage the B and C values of state pair (n0, n0+1) for logical positions [base, base + SC_CHUNK) into LDS tiles
-// laid out [lane j][item i][state 0/1] (fp32, row stride SC_ROW).  Whole workgroup cooperates.
+// ---- B/C tile staging: global -> registers (prefetch) -> LDS ----------------------------------------------------------
+// Thread t of the 256-thread workgroup owns tensor (t >> 7) (0 = B, 1 = C) and the 8 logical positions
+// base + 8 * (t & 127) .. +8 of BOTH states of the pair.  Tile layout in LDS: [lane j][item i][state 0/1] fp32 with
+// row stride SC_ROW, i.e. the 16 floats a staging thread writes are contiguous (4 x ds_write_b128).
 template <typename T>
-__device__ __forceinline__ void sc_stage_bc(float* tB, float* tC, const T* Bm, const T* Cm, int n0, int N, int64_t SB,
-                                            int64_t sb, int64_t base, int64_t L, int rev) {
-    for (int idx = threadIdx.x; idx < 2 * SC_CHUNK; idx += blockDim.x) {
-        const int s = idx / SC_CHUNK;
-        const int tok = idx - s * SC_CHUNK;
-        const int64_t p = base + tok;
-        float bv = 0.f, cv = 0.f;
-        if (p < L && n0 + s < N) {
-            const int64_t off = ((int64_t)(n0 + s) * SB + sb) * L + cad_phys(p, L, rev);
-            bv = to_f32(Bm[off]);
-            cv = to_f32(Cm[off]);
+struct __attribute__((aligned(sizeof(T) * SC_SV >= 16 ? 16 : 8))) StVec {
+    T v[SC_SV];
+};
+template <typename T>
+struct StageRegs {
+    StVec<T> s0, s1;
+};
+
+template <typename T>
+__device__ __forceinline__ void sc_stage_load(StageRegs<T>& r, const T* Bm, const T* Cm, int n0, int N, int64_t SB,
+                                              int64_t sb, int64_t base, int64_t L, int rev, bool vec_ok) {
+    const int t = threadIdx.x;
+    const T* src = (t >> 7) ? Cm : Bm;
+    const int64_t p0 = base + (int64_t)(t & 127) * SC_SV;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        StVec<T>& dst = s ? r.s1 : r.s0;
+        const T* row = src + ((int64_t)(n0 + s) * SB + sb) * L;
+        if (n0 + s < N && vec_ok && p0 + SC_SV <= L) {
+            const int64_t l0 = rev ? (L - p0 - SC_SV) : p0;
+            dst = *(const StVec<T>*)(row + l0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SC_SV; ++j) {
+                const int64_t p = p0 + j;
+                const int k = rev ? (SC_SV - 1 - j) : j;
+                if (n0 + s < N && p < L)
+                    dst.v[k] = row[cad_phys(p, L, rev)];
+                else
+                    dst.v[k] = from_f32<T>(0.f);
+            }
         }
-        const int o = (tok / SC_S) * SC_ROW + (tok % SC_S) * 2 + s;
-        tB[o] = bv;
-        tC[o] = cv;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void sc_stage_store(const StageRegs<T>& r, float* tiles /* B tile, C tile follows */, int rev) {
+    const int t = threadIdx.x;
+    float* tile = tiles + (t >> 7) * SC_TILE;
+    const int tok = (t & 127) * SC_SV;  // position inside the chunk
+    float* dst = tile + (tok / SC_S) * SC_ROW + (tok % SC_S) * 2;
+#pragma unroll
+    for (int j = 0; j < SC_SV; ++j) {
+        const int k = rev ? (SC_SV - 1 - j) : j;
+        dst[2 * j] = to_f32(r.s0.v[k]);
+        dst[2 * j + 1] = to_f32(r.s1.v[k]);
     }
 }

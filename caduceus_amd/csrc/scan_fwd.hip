@@ -1,11 +1,17 @@
-// Selective SSM scan, forward (include/caduceus_hip.h, cad_scan_fwd).  See scan_common.h for the decomposition.
+// Selective SSM scan, forward (include/caduceus_hip.h, cad_scan_fwd / cad_scan_fwd_multi).
+// See scan_common.h for the decomposition.
 #include "scan_common.h"
 
 namespace {
 
+struct ScanFwdSets {
+    cad_scan_args s[SC_MAXSETS];
+};
+
 template <typename T>
-__global__ __launch_bounds__(64 * SC_W) void scan_fwd_kernel(cad_scan_args a) {
+__global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE]
+    const cad_scan_args& a = sets.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t sb = blockIdx.y;
@@ -23,18 +29,35 @@ __global__ __launch_bounds__(64 * SC_W) void scan_fwd_kernel(cad_scan_args a) {
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
     const bool vec_ok = ((L * sizeof(T)) % 16) == 0 &&
-                        (((uintptr_t)a.u | (uintptr_t)a.delta | (uintptr_t)a.z | (uintptr_t)a.out) % 16) == 0;
+                        (((uintptr_t)a.u | (uintptr_t)a.delta | (uintptr_t)a.z | (uintptr_t)a.out | (uintptr_t)a.Bm |
+                          (uintptr_t)a.Cm) % 16) == 0;
     const float Dv = a.D ? a.D[e] : 0.f;
     const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
 
+    // software pipeline: the B/C tile of the NEXT (chunk, pair) and the u/delta/z vectors of the NEXT chunk are in
+    // flight (registers) while the current pair is computed.
+    StageRegs<T> st;
+    ScVec<T> u_raw, d_raw, z_raw;
+    sc_stage_load(st, Bm, Cm, 0, N, SB, sb, 0, L, rev, vec_ok);
+    sc_load_raw(u_row, (int64_t)lane * SC_S, L, rev, vec_ok, u_raw);
+    sc_load_raw(d_row, (int64_t)lane * SC_S, L, rev, vec_ok, d_raw);
+    sc_stage_store(st, smem, rev);
+    __syncthreads();
+
     f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
+    int tix = 0;            // tiles consumed so far: tile tix lives in LDS buffer tix & 1
     for (int64_t c = 0; c < nchunks; ++c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float du[SC_S], dt[SC_S], y[SC_S];
-        sc_load(u_row, p0, L, rev, vec_ok, du);
-        sc_load(d_row, p0, L, rev, vec_ok, dt);
+        sc_unpack(u_raw, rev, du);
+        sc_unpack(d_raw, rev, dt);
+        if (z_row) sc_load_raw(z_row, p0, L, rev, vec_ok, z_raw);
+        if (c + 1 < nchunks) {
+            sc_load_raw(u_row, p0 + SC_CHUNK, L, rev, vec_ok, u_raw);
+            sc_load_raw(d_row, p0 + SC_CHUNK, L, rev, vec_ok, d_raw);
+        }
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             dt[i] = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
@@ -42,17 +65,19 @@ __global__ __launch_bounds__(64 * SC_W) void scan_fwd_kernel(cad_scan_args a) {
             du[i] *= dt[i];
         }
         if (a.chunk_state && act && lane < NP) {
-            float* st = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
-            st[0] = carry[0];
-            st[1] = carry[1];
+            float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
+            stp[0] = carry[0];
+            stp[1] = carry[1];
         }
-        sc_stage_bc(smem, smem + SC_TILE, Bm, Cm, 0, N, SB, sb, base, L, rev);
-        __syncthreads();
-        for (int np = 0; np < NP; ++np) {
-            const int buf = np & 1;
-            if (np + 1 < NP)
-                sc_stage_bc(smem + (buf ^ 1) * 2 * SC_TILE, smem + (buf ^ 1) * 2 * SC_TILE + SC_TILE, Bm, Cm,
-                            2 * (np + 1), N, SB, sb, base, L, rev);
+        for (int np = 0; np < NP; ++np, ++tix) {
+            const int buf = tix & 1;
+            // prefetch the next tile: pair np+1 of this chunk, or pair 0 of the next chunk
+            const bool more = (np + 1 < NP) || (c + 1 < nchunks);
+            if (more) {
+                const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
+                const int64_t nb = (np + 1 < NP) ? base : base + SC_CHUNK;
+                sc_stage_load(st, Bm, Cm, nn, N, SB, sb, nb, L, rev, vec_ok);
+            }
             const float* tB = smem + buf * 2 * SC_TILE + lane * SC_ROW;
             const float* tC = tB + SC_TILE;
             const int n0 = 2 * np;
@@ -69,36 +94,27 @@ __global__ __launch_bounds__(64 * SC_W) void scan_fwd_kernel(cad_scan_args a) {
                 ha[i] = acc_a;
                 hh[i] = acc_h;
             }
-            // (ii) inclusive Kogge-Stone scan of the affine maps across lanes
+            // (ii) inclusive scan of the affine maps across lanes (DPP)
             f32x2 PA = acc_a, PH = acc_h;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const f32x2 ua = shfl_up2(PA, d), uh = shfl_up2(PH, d);
-                if (lane >= d) {
-                    PH = PA * uh + PH;
-                    PA = PA * ua;
-                }
-            }
-            f32x2 ea = shfl_up2(PA, 1), eh = shfl_up2(PH, 1);
-            if (lane == 0) {
-                ea = f2(1.f);
-                eh = f2(0.f);
-            }
+            wave_scan_fwd(PA, PH);
+            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
+            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
             // (iii) carry in / out
-            const f32x2 hin = shfl2(carry, np);
+            const f32x2 hin = readlane2(carry, np);
             const f32x2 h0 = ea * hin + eh;
-            const f32x2 newc = shfl2(PA * hin + PH, 63);
+            const f32x2 newc = readlane2(PA * hin + PH, 63);
             if (lane == np) carry = newc;
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const f32x2 h = ha[i] * h0 + hh[i];
                 y[i] += dot2(ld2(tC + 2 * i), h);
             }
+            if (more) sc_stage_store(st, smem + (buf ^ 1) * 2 * SC_TILE, rev);
             __syncthreads();
         }
         if (z_row) {
             float zz[SC_S];
-            sc_load(z_row, p0, L, rev, vec_ok, zz);
+            sc_unpack(z_raw, rev, zz);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) y[i] *= zz[i] * cad_sigmoid(zz[i]);
         }
@@ -115,18 +131,30 @@ extern "C" int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N) {
     return (int64_t)E * SB * nchunks * ((N + 1) / 2) * 2;
 }
 
-extern "C" int cad_scan_fwd(const cad_scan_args* a, void* stream) {
-    CAD_CHECK_ARG(a && a->u && a->delta && a->A && a->Bm && a->Cm && a->out);
-    CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
-    CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
+extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream) {
+    CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= SC_MAXSETS);
+    ScanFwdSets ks;
+    for (int i = 0; i < nsets; ++i) {
+        const cad_scan_args* a = &sets[i];
+        CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && a->out);
+        CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
+        CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
+        CAD_CHECK_ARG(a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L && a->N == sets[0].N &&
+                      a->dtype == sets[0].dtype);
+        ks.s[i] = *a;
+    }
+    for (int i = nsets; i < SC_MAXSETS; ++i) ks.s[i] = sets[0];
+    const cad_scan_args* a = &sets[0];
     CadProfScope prof(0, stream);
-    dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB), block(64 * SC_W);
+    dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const size_t shmem = (size_t)4 * SC_TILE * sizeof(float);
     if (a->dtype == CAD_F32)
-        CAD_LAUNCH((scan_fwd_kernel<float>), grid, block, shmem, stream, *a);
+        CAD_LAUNCH((scan_fwd_kernel<float>), grid, block, shmem, stream, ks);
     else if (a->dtype == CAD_BF16)
-        CAD_LAUNCH((scan_fwd_kernel<bf16_t>), grid, block, shmem, stream, *a);
+        CAD_LAUNCH((scan_fwd_kernel<bf16_t>), grid, block, shmem, stream, ks);
     else
         return CAD_ERR_UNSUPPORTED;
     return cad_after_launch();
 }
+
+extern "C" int cad_scan_fwd(const cad_scan_args* a, void* stream) { return cad_scan_fwd_multi(a, 1, stream); }

@@ -27,20 +27,18 @@ def _w(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t if t.dtype == dtype else t.to(dtype)
 
 
-def _one_param_set(xz: torch.Tensor, m, split: int, rev_lo: int, rev_hi: int, act: torch.dtype) -> torch.Tensor:
-    """conv -> x_proj -> dt_proj -> scan for one Mamba parameter set `m` on channel-major xz (2E, SB, L).
-    Math: SURVEY.md section 7.2 (upstream mamba_inner_fn).  Returns gated y (E, SB, L)."""
+def _scan_inputs(xz: torch.Tensor, m, split: int, rev_lo: int, rev_hi: int, act: torch.dtype):
+    """conv -> x_proj -> dt_proj for one Mamba parameter set `m` on channel-major xz (2E, SB, L): the operands of the
+    selective scan.  Math: SURVEY.md section 7.2 (upstream mamba_inner_fn)."""
     E2, SB, L = xz.shape
     E = E2 // 2
     T = SB * L
     N, R = m.d_state, m.dt_rank
-    x, z = xz[:E], xz[E:]
-    xc = ops.causal_conv1d(x, m.conv1d.weight, m.conv1d.bias, split, rev_lo, rev_hi)
+    xc = ops.causal_conv1d(xz[:E], m.conv1d.weight, m.conv1d.bias, split, rev_lo, rev_hi)
     dbc = torch.mm(_w(m.x_proj.weight, act), xc.view(E, T)).view(R + 2 * N, SB, L)
     delta = torch.mm(_w(m.dt_proj.weight, act), dbc[:R].reshape(R, T)).view(E, SB, L)
     A = -torch.exp(m.A_log.float())
-    return ops.selective_scan(xc, delta, A, dbc[R:R + N], dbc[R + N:], m.D.float(), z, m.dt_proj.bias.float(), split,
-                              rev_lo, rev_hi)
+    return (xc, delta, A, dbc[R:R + N], dbc[R + N:], m.D.float(), m.dt_proj.bias.float())
 
 
 def _in_proj(m, x2d: torch.Tensor, SB: int, L: int, act: torch.dtype) -> torch.Tensor:
@@ -70,12 +68,19 @@ def bimamba_tframe(hn: torch.Tensor, mamba_fwd, mamba_rev, strategy: Optional[st
     x2d = hn.reshape(T, D)
     split = B if (S == 2 and strand_swap) else SB
     xz_f = _in_proj(mamba_fwd, x2d, SB, L, act)
-    y_f = _one_param_set(xz_f, mamba_fwd, split, 0, 1, act)
+    E = xz_f.shape[0] // 2
+    set_f = _scan_inputs(xz_f, mamba_fwd, split, 0, 1, act)
     if mamba_rev is None:
+        y_f = ops.selective_scan_multi([set_f], xz_f[E:], split, [(0, 1)])[0]
         return _out_proj(mamba_fwd, y_f, None, act).view(S, B, L, D)
     tied_in = mamba_rev.in_proj.weight is mamba_fwd.in_proj.weight and mamba_rev.in_proj.bias is mamba_fwd.in_proj.bias
     xz_r = xz_f if tied_in else _in_proj(mamba_rev, x2d, SB, L, act)
-    y_r = _one_param_set(xz_r, mamba_rev, split, 1, 0, act)
+    set_r = _scan_inputs(xz_r, mamba_rev, split, 1, 0, act)
+    if tied_in:  # both parameter sets share the gate z: ONE launch runs the forward- and reverse-direction scans
+        y_f, y_r = ops.selective_scan_multi([set_f, set_r], xz_f[E:], split, [(0, 1), (1, 0)])
+    else:
+        y_f = ops.selective_scan_multi([set_f], xz_f[E:], split, [(0, 1)])[0]
+        y_r = ops.selective_scan_multi([set_r], xz_r[E:], split, [(1, 0)])[0]
     strategy = strategy or "add"
     if strategy == "add":
         tied_out = (mamba_rev.out_proj.weight is mamba_fwd.out_proj.weight and mamba_fwd.out_proj.bias is None

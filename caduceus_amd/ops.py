@@ -8,6 +8,7 @@ memory, streams and the autograd graph; all arithmetic of these ops happens in t
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -161,59 +162,101 @@ def causal_conv1d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
 # ------------------------------------------------------------------------------------------------------------------
 # selective scan
 # ------------------------------------------------------------------------------------------------------------------
-class _Scan(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, split, rev_lo, rev_hi):
-        u, delta, Bm, Cm = u.contiguous(), delta.contiguous(), Bm.contiguous(), Cm.contiguous()
-        z = None if z is None else z.contiguous()
-        E, SB, Lq = u.shape
-        N = A.shape[1]
-        Af = A.float().contiguous()
-        Df = D.float().contiguous()
-        bf = delta_bias.float().contiguous()
-        out = torch.empty_like(u)
-        lib = L.get_lib()
-        need_grad = any(ctx.needs_input_grad)
-        state = (torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
-                 if need_grad else None)
-        stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, out, state)
-        if delta.dtype != u.dtype or Bm.dtype != u.dtype or Cm.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
-            raise TypeError("selective_scan: u, delta, B, C, z must share one dtype")
-        a = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
-                       L.ptr(out), L.ptr(state), SB, Lq, split, E, N, rev_lo, rev_hi, L.dtype_code(u.dtype))
-        L.check(lib.cad_scan_fwd(C.byref(a), stream), "cad_scan_fwd")
-        ctx.save_for_backward(u, delta, Af, Bm, Cm, Df, z, bf, state)
-        ctx.meta = (split, rev_lo, rev_hi, A.dtype, D.dtype, delta_bias.dtype)
-        return out
+SCAN_PARTIALS = int(os.environ.get("CADUCEUS_AMD_SCAN_PARTIALS", "8"))  # 8: per-XCD L2 atomics for dB/dC; 1: device scope
+
+
+class _ScanMulti(torch.autograd.Function):
+    """1 or 2 parameter sets (same shapes, shared gate z) in one launch.  Tensor args per set:
+    u, delta, A, Bm, Cm, D, delta_bias."""
 
     @staticmethod
-    def backward(ctx, dout):
-        u, delta, Af, Bm, Cm, Df, z, bf, state = ctx.saved_tensors
-        split, rev_lo, rev_hi, Adt, Ddt, bdt = ctx.meta
-        E, SB, Lq = u.shape
-        N = Af.shape[1]
-        dout = dout.contiguous()
-        du, ddelta = torch.empty_like(u), torch.empty_like(u)
-        dz = None if z is None else torch.empty_like(u)
-        dA = torch.zeros_like(Af)
-        dB = torch.zeros((N, SB, Lq), dtype=torch.float32, device=u.device)
-        dC = torch.zeros((N, SB, Lq), dtype=torch.float32, device=u.device)
-        dD = torch.zeros_like(Df)
-        dbias = torch.zeros_like(bf)
-        stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dB, dC, dD, dbias)
-        a = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
-                          L.ptr(dout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz), L.ptr(dA), L.ptr(dB),
-                          L.ptr(dC), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N, rev_lo, rev_hi,
-                          L.dtype_code(u.dtype))
-        L.check(L.get_lib().cad_scan_bwd(C.byref(a), stream), "cad_scan_bwd")
-        return (du, ddelta, dA.to(Adt), dB.to(u.dtype), dC.to(u.dtype), dD.to(Ddt), dz, dbias.to(bdt), None, None,
-                None)
+    def forward(ctx, z, split, dirs, *tensors):
+        nsets = len(tensors) // 7
+        lib = L.get_lib()
+        z = None if z is None else z.contiguous()
+        sets, args = [], (L.ScanArgs * nsets)()
+        need_grad = any(ctx.needs_input_grad)
+        outs = []
+        for i in range(nsets):
+            u, delta, A, Bm, Cm, D, bias = tensors[7 * i:7 * i + 7]
+            u, delta, Bm, Cm = u.contiguous(), delta.contiguous(), Bm.contiguous(), Cm.contiguous()
+            if delta.dtype != u.dtype or Bm.dtype != u.dtype or Cm.dtype != u.dtype or \
+                    (z is not None and z.dtype != u.dtype):
+                raise TypeError("selective_scan: u, delta, B, C, z must share one dtype")
+            E, SB, Lq = u.shape
+            N = A.shape[1]
+            Af, Df, bf = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
+            out = torch.empty_like(u)
+            state = (torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
+                     if need_grad else None)
+            stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, out, state)
+            rl, rh = dirs[i]
+            args[i] = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
+                                 L.ptr(out), L.ptr(state), SB, Lq, split, E, N, rl, rh, L.dtype_code(u.dtype))
+            sets.append((u, delta, Af, Bm, Cm, Df, bf, state))
+            outs.append(out)
+        L.check(lib.cad_scan_fwd_multi(args, nsets, stream), "cad_scan_fwd_multi")
+        flat = [t for s_ in sets for t in s_]
+        ctx.save_for_backward(z, *flat)
+        ctx.meta = (split, dirs, nsets, [(t[2].dtype, t[5].dtype, t[6].dtype) for t in
+                                         [tensors[7 * i:7 * i + 7] for i in range(nsets)]])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        z, *flat = ctx.saved_tensors
+        split, dirs, nsets, pdt = ctx.meta
+        lib = L.get_lib()
+        args = (L.ScanBwdArgs * nsets)()
+        keep, res = [], []
+        npart = SCAN_PARTIALS
+        for i in range(nsets):
+            u, delta, Af, Bm, Cm, Df, bf, state = flat[8 * i:8 * i + 8]
+            E, SB, Lq = u.shape
+            N = Af.shape[1]
+            dout = douts[i].contiguous()
+            du, ddelta = torch.empty_like(u), torch.empty_like(u)
+            dz = None if z is None else torch.empty_like(u)
+            dA, dD, dbias = torch.zeros_like(Af), torch.zeros_like(Df), torch.zeros_like(bf)
+            dBC = torch.zeros((2, npart, N, SB, Lq), dtype=torch.float32, device=u.device)
+            stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dBC, dD, dbias)
+            rl, rh = dirs[i]
+            args[i] = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
+                                    L.ptr(bf), L.ptr(dout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz),
+                                    L.ptr(dA), L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
+                                    rl, rh, L.dtype_code(u.dtype), npart)
+            keep.append((dout, dBC))
+            res.append([du, ddelta, dA, dBC, dD, dbias, dz])
+        L.check(lib.cad_scan_bwd_multi(args, nsets, stream), "cad_scan_bwd_multi")
+        grads = []
+        dz_tot = None
+        for i in range(nsets):
+            du, ddelta, dA, dBC, dD, dbias, dz = res[i]
+            u = flat[8 * i]
+            n = dBC[0, 0].numel()
+            dB, dC = torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device), \
+                torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device)
+            for src, dst in ((dBC[0], dB), (dBC[1], dC)):
+                L.check(lib.cad_reduce_partials(L.ptr(src), npart, n, L.ptr(dst), L.dtype_code(u.dtype), stream),
+                        "cad_reduce_partials")
+            Adt, Ddt, bdt = pdt[i]
+            grads += [du, ddelta, dA.to(Adt), dB, dC, dD.to(Ddt), dbias.to(bdt)]
+            if dz is not None:
+                dz_tot = dz if dz_tot is None else dz_tot.add_(dz)
+        return (dz_tot, None, None, *grads)
+
+
+def selective_scan_multi(sets, z, split: int, dirs):
+    """sets: list of (u, delta, A, Bm, Cm, D, delta_bias) with u, delta: (E, SB, L); A: (E, N) (= -exp(A_log));
+    Bm, Cm: (N, SB, L); D, delta_bias: (E).  z: shared gate (E, SB, L) or None.  dirs: [(rev_lo, rev_hi)] per set.
+    mamba_ssm `selective_scan_fn(..., delta_softplus=True)` for each set, each row in its own direction."""
+    flat = [t for s_ in sets for t in s_]
+    return _ScanMulti.apply(z, int(split), tuple((int(a), int(b)) for a, b in dirs), *flat)
 
 
 def selective_scan(u, delta, A, Bm, Cm, D, z, delta_bias, split: int, rev_lo: int, rev_hi: int) -> torch.Tensor:
-    """u, delta, z: (E, SB, L); A: (E, N) (= -exp(A_log)); Bm, Cm: (N, SB, L); D, delta_bias: (E).
-    mamba_ssm `selective_scan_fn(..., delta_softplus=True)` per row in its own direction."""
-    return _Scan.apply(u, delta, A, Bm, Cm, D, z, delta_bias, int(split), int(rev_lo), int(rev_hi))
+    """Single parameter set (see selective_scan_multi)."""
+    return selective_scan_multi([(u, delta, A, Bm, Cm, D, delta_bias)], z, split, [(rev_lo, rev_hi)])[0]
 
 
 # ------------------------------------------------------------------------------------------------------------------

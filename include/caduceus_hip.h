@@ -186,10 +186,15 @@ typedef struct {
     int dtype;
 } cad_scan_args;
 int cad_scan_fwd(const cad_scan_args* a, void* stream);
+/* Same, for nsets (1 or 2) independent parameter sets of identical shape in ONE launch -- the mamba_fwd and mamba_rev
+ * scans of a BiMamba layer (modeling_caduceus.py:128-130) -- so that a CU holds two waves per SIMD even at batch 1. */
+int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream);
 int64_t cad_scan_chunk_len(void);
 int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
-/* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E), dB, dC ((N,SB,L) fp32) are
- * ACCUMULATED with fp32 atomics (caller zeroes; summation order over channels is not deterministic). */
+/* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E) are ACCUMULATED with fp32 atomics
+ * (caller zeroes).  dB, dC: n_partials fp32 buffers of (N,SB,L) each, ACCUMULATED (caller zeroes; summation order over
+ * channels is not deterministic).  n_partials = 1: one buffer, device-scope atomics.  n_partials = 8: one buffer per
+ * XCD, atomics resolved in that XCD's L2; fold them with cad_reduce_partials. */
 typedef struct {
     const void* u;
     const void* delta;
@@ -213,8 +218,12 @@ typedef struct {
     int E, N;
     int rev_lo, rev_hi;
     int dtype;
+    int n_partials;
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
+int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
+/* dst[i] = sum_k src[k*n + i], k < n_partials; dst in dst_dtype (fp32 or bf16). */
+int cad_reduce_partials(const float* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()

@@ -6,7 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "caduceus_amd", "csrc")
-LIB = os.path.join(HERE, "libcaduceus_emu.so")
+# CAD_EMU_DEFINES="SC_S=8" builds (and names) a tuning variant of the emulated library
+_DEFS = [d for d in os.environ.get("CAD_EMU_DEFINES", "").split() if d]
+LIB = os.path.join(HERE, "libcaduceus_emu" + ("_" + "_".join(d.replace("=", "") for d in _DEFS) if _DEFS else "") + ".so")
 
 
 def build_emu(force: bool = False) -> str:
@@ -15,9 +17,10 @@ def build_emu(force: bool = False) -> str:
         [os.path.join(ROOT, "include", "caduceus_hip.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", os.path.basename(LIB))
     os.makedirs(objdir, exist_ok=True)
     flags = ["-O2", "-std=c++17", "-fPIC", "-DCAD_EMU", "-I", HERE, "-Wno-attributes", "-Wno-unknown-pragmas"]
+    flags += [f"-D{d}" for d in _DEFS]
     procs = []
     for s in srcs:
         obj = os.path.join(objdir, os.path.basename(s) + ".o")

@@ -61,6 +61,23 @@ def main():
     t = timeit(bwd, a.reps)
     res["scan_bwd_ms"] = t
     res["scan_bwd_GBps"] = (7 * E + 4 * N) * s * T / t / 1e6
+    # production path: both parameter sets of a BiMamba layer in one launch
+    u2, d2, B2, C2 = r(E, SB, L), r(E, SB, L), r(N, SB, L), r(N, SB, L)
+    sets = [(u, delta, A, Bm, Cm, D, bias), (u2, d2, A, B2, C2, D, bias)]
+    sp = SB // 2 or SB
+    t = timeit(lambda: ops.selective_scan_multi(sets, z, sp, [(0, 1), (1, 0)]), a.reps)
+    res["scan_fwd2_ms"] = t
+    res["scan_fwd2_GBps"] = 2 * (4 * E + 2 * N) * s * T / t / 1e6
+    gsets = [tuple(x.clone().requires_grad_(True) for x in st) for st in sets]
+    zg = z.clone().requires_grad_(True)
+    o1, o2 = ops.selective_scan_multi(gsets, zg, sp, [(0, 1), (1, 0)])
+    g1, g2 = torch.randn_like(o1), torch.randn_like(o2)
+
+    def bwd2():
+        torch.autograd.backward([o1, o2], [g1, g2], retain_graph=True)
+    t = timeit(bwd2, a.reps)
+    res["scan_bwd2_ms"] = t
+    res["scan_bwd2_GBps"] = 2 * (7 * E + 4 * N) * s * T / t / 1e6
     t = timeit(lambda: ops.causal_conv1d(u, w, cb, SB // 2 or SB, 0, 1), a.reps)
     res["conv_fwd_ms"] = t
     res["conv_fwd_GBps"] = 2 * E * s * T / t / 1e6
