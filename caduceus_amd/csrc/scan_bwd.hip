@@ -22,7 +22,7 @@ struct ScanBwdSets {
 
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum1(v[0]), wave_sum1(v[1])); }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE] inputs, then [2 buffers][dB,dC][SC_TILE] accumulators
     const cad_scan_bwd_args& a = sets.s[blockIdx.z];
@@ -46,10 +46,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     T* dz_row = a.dz ? (T*)a.dz + row_off : nullptr;
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
-    const bool vec_ok =
-        ((L * sizeof(T)) % 16) == 0 &&
-        (((uintptr_t)a.u | (uintptr_t)a.delta | (uintptr_t)a.z | (uintptr_t)a.dout | (uintptr_t)a.du |
-          (uintptr_t)a.ddelta | (uintptr_t)a.dz | (uintptr_t)a.Bm | (uintptr_t)a.Cm) % 16) == 0;
     const float Dv = a.D ? a.D[e] : 0.f;
     const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
@@ -66,15 +62,21 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     ScVec<T> u_raw, d_raw, g_raw, z_raw;
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
-        sc_stage_load(st, Bm, Cm, 0, N, SB, sb, base, L, rev, vec_ok);
-        sc_load_raw(u_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, u_raw);
-        sc_load_raw(d_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, d_raw);
-        sc_load_raw(g_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, g_raw);
-        if (z_row) sc_load_raw(z_row, base + (int64_t)lane * SC_S, L, rev, vec_ok, z_raw);
+        sc_stage_load<T, VEC>(st, Bm, Cm, 0, N, SB, sb, base, L, rev);
+        sc_load_raw<T, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
+        sc_load_raw<T, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
+        sc_load_raw<T, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
+        if (z_row) sc_load_raw<T, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
         sc_stage_store(st, smem, rev);
     }
     __syncthreads();
 
+    // lane np holds (A[2np], A[2np+1]); broadcast per pair with v_readlane (no memory access in the pair loop)
+    f32x2 Areg = f2(0.f);
+    if (lane < NP) {
+        const int n0 = 2 * lane;
+        Areg = f2(a.A[e * N + n0], (n0 + 1 < N) ? a.A[e * N + n0 + 1] : 0.f);
+    }
     f32x2 carryG = f2(0.f);  // lane np: G flowing out of the later chunk into this one, for pair np
     f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
     float dDacc = 0.f, dbacc = 0.f;
@@ -84,9 +86,16 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float uu[SC_S], dt[SC_S], dy[SC_S], ddt[SC_S], ddu[SC_S], y[SC_S];
+        f32x2 dd[SC_S], ee[SC_S];  // (dt, dt * u) and (dy, u)
         sc_unpack(u_raw, rev, uu);
         sc_unpack(d_raw, rev, dt);
         sc_unpack(g_raw, rev, dy);
+        // chunk-start states of all pairs (saved by the forward): lane np fetches pair np, broadcast by v_readlane
+        f32x2 hin_reg = f2(0.f);
+        if (lane < NP) {
+            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
+            hin_reg = f2(stp[0], stp[1]);
+        }
         if (z_row) {
             float zz[SC_S];
             sc_unpack(z_raw, rev, zz);
@@ -94,20 +103,22 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
         }
         if (c > 0) {  // prefetch the item vectors of the next (earlier) chunk
-            sc_load_raw(u_row, p0 - SC_CHUNK, L, rev, vec_ok, u_raw);
-            sc_load_raw(d_row, p0 - SC_CHUNK, L, rev, vec_ok, d_raw);
-            sc_load_raw(g_row, p0 - SC_CHUNK, L, rev, vec_ok, g_raw);
-            if (z_row) sc_load_raw(z_row, p0 - SC_CHUNK, L, rev, vec_ok, z_raw);
+            sc_load_raw<T, VEC>(u_row, p0 - SC_CHUNK, L, rev, u_raw);
+            sc_load_raw<T, VEC>(d_row, p0 - SC_CHUNK, L, rev, d_raw);
+            sc_load_raw<T, VEC>(g_row, p0 - SC_CHUNK, L, rev, g_raw);
+            if (z_row) sc_load_raw<T, VEC>(z_row, p0 - SC_CHUNK, L, rev, z_raw);
         }
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const bool ok = p0 + i < L;
-            dt[i] = ok ? cad_softplus(dt[i] + bias) : 0.f;
-            dy[i] = ok ? dy[i] * keep : 0.f;
+            const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
+            const float dyi = ok ? dy[i] * keep : 0.f;
             y[i] = Dv * uu[i];
             ddt[i] = 0.f;
-            ddu[i] = dy[i] * Dv;
-            dDacc += dy[i] * uu[i];
+            ddu[i] = dyi * Dv;
+            dDacc += dyi * uu[i];
+            dd[i] = f2(dti, dti * uu[i]);
+            ee[i] = f2(dyi, uu[i]);
         }
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
@@ -115,24 +126,23 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
-                sc_stage_load(st, Bm, Cm, nn, N, SB, sb, nb, L, rev, vec_ok);
+                sc_stage_load<T, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
             }
             const float* tB = smem + buf * 2 * SC_TILE + lane * SC_ROW;
             const float* tC = tB + SC_TILE;
             float* aB = acc + buf * 2 * SC_TILE + lane * SC_ROW;
             float* aC = aB + SC_TILE;
             const int n0 = 2 * np;
-            const f32x2 Av = f2(a.A[e * N + n0], (n0 + 1 < N) ? a.A[e * N + n0 + 1] : 0.f);
+            const f32x2 Av = readlane2(Areg, np);
             const f32x2 A2 = Av * f2(CAD_LOG2E);
-            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + np) * 2;
-            const f32x2 hin = f2(stp[0], stp[1]);
+            const f32x2 hin = readlane2(hin_reg, np);
             // 1. forward recompute: serial totals, wave scan, then the true h_i
             f32x2 av[SC_S], hs[SC_S];
             f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
-                av[i] = exp2_2(f2(dt[i]) * A2);
-                hs[i] = f2(dt[i] * uu[i]) * ld2(tB + 2 * i);  // b_i
+                av[i] = exp2_2(splat_lo(dd[i]) * A2);
+                hs[i] = splat_hi(dd[i]) * ld2(tB + 2 * i);  // b_i
                 acc_h = av[i] * acc_h + hs[i];
                 acc_a = acc_a * av[i];
             }
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // 2. reverse scan of G
             f32x2 RG = f2(0.f);
 #pragma unroll
-            for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (ld2(tC + 2 * i) * f2(dy[i]) + RG);
+            for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (ld2(tC + 2 * i) * splat_lo(ee[i]) + RG);
             f32x2 QA = acc_a, QG = RG;
             wave_scan_rev(QA, QG, lane);
             const f32x2 fa = f2(dpp_wave_shl1(1.f, QA[0]), dpp_wave_shl1(1.f, QA[1]));
@@ -167,16 +177,16 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 #pragma unroll
             for (int i = SC_S - 1; i >= 0; --i) {
                 const f32x2 Bv = ld2(tB + 2 * i);
-                const f32x2 g = ld2(tC + 2 * i) * f2(dy[i]) + G;
+                const f32x2 g = ld2(tC + 2 * i) * splat_lo(ee[i]) + G;
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = g * hprev * av[i];
                 const float gB = dot2(g, Bv);
-                ddt[i] += dot2(t, Av) + uu[i] * gB;
-                ddu[i] += dt[i] * gB;
-                dAp = dAp + t * f2(dt[i]);
-                const f32x2 dBv = g * f2(dt[i] * uu[i]);
-                const f32x2 dCv = hs[i] * f2(dy[i]);
+                ddt[i] += dot2(t, Av) + ee[i][1] * gB;
+                ddu[i] += dd[i][0] * gB;
+                dAp = dAp + t * splat_lo(dd[i]);
+                const f32x2 dBv = g * splat_hi(dd[i]);
+                const f32x2 dCv = hs[i] * splat_lo(ee[i]);
                 atomicAdd(aB + 2 * i, dBv[0]);
                 atomicAdd(aB + 2 * i + 1, dBv[1]);
                 atomicAdd(aC + 2 * i, dCv[0]);
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         }
         // per-item outputs of this chunk (delta / z / dout are re-read: still L2-resident, keeps 48 VGPRs free)
         float dl[SC_S];
-        sc_load(d_row, p0, L, rev, vec_ok, dl);
+        sc_load<T, VEC>(d_row, p0, L, rev, dl);
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const float xraw = dl[i] + bias;
@@ -225,19 +235,19 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             dbacc += ddt[i];
         }
         if (act) {
-            sc_store(du_row, p0, L, rev, vec_ok, ddu);
-            sc_store(dd_row, p0, L, rev, vec_ok, ddt);
+            sc_store<T, VEC>(du_row, p0, L, rev, ddu);
+            sc_store<T, VEC>(dd_row, p0, L, rev, ddt);
         }
         if (dz_row) {
             float zz[SC_S], go[SC_S];
-            sc_load(z_row, p0, L, rev, vec_ok, zz);
-            sc_load(g_row, p0, L, rev, vec_ok, go);
+            sc_load<T, VEC>(z_row, p0, L, rev, zz);
+            sc_load<T, VEC>(g_row, p0, L, rev, go);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const float sg = cad_sigmoid(zz[i]);
                 go[i] = go[i] * y[i] * sg * (1.f + zz[i] * (1.f - sg));
             }
-            if (act) sc_store(dz_row, p0, L, rev, vec_ok, go);
+            if (act) sc_store<T, VEC>(dz_row, p0, L, rev, go);
         }
     }
     // per-channel parameter gradients
@@ -284,15 +294,27 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     }
     for (int i = nsets; i < SC_MAXSETS; ++i) ks.s[i] = sets[0];
     const cad_scan_bwd_args* a = &sets[0];
+    bool vec = (a->L % SC_S) == 0;
+    for (int i = 0; i < nsets; ++i)
+        vec = vec && (((uintptr_t)sets[i].u | (uintptr_t)sets[i].delta | (uintptr_t)sets[i].z | (uintptr_t)sets[i].dout |
+                       (uintptr_t)sets[i].du | (uintptr_t)sets[i].ddelta | (uintptr_t)sets[i].dz |
+                       (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm) % 16) == 0;
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const size_t shmem = (size_t)8 * SC_TILE * sizeof(float);
-    if (a->dtype == CAD_F32)
-        CAD_LAUNCH((scan_bwd_kernel<float>), grid, block, shmem, stream, ks);
-    else if (a->dtype == CAD_BF16)
-        CAD_LAUNCH((scan_bwd_kernel<bf16_t>), grid, block, shmem, stream, ks);
-    else
+    if (a->dtype == CAD_F32) {
+        if (vec)
+            CAD_LAUNCH((scan_bwd_kernel<float, true>), grid, block, shmem, stream, ks);
+        else
+            CAD_LAUNCH((scan_bwd_kernel<float, false>), grid, block, shmem, stream, ks);
+    } else if (a->dtype == CAD_BF16) {
+        if (vec)
+            CAD_LAUNCH((scan_bwd_kernel<bf16_t, true>), grid, block, shmem, stream, ks);
+        else
+            CAD_LAUNCH((scan_bwd_kernel<bf16_t, false>), grid, block, shmem, stream, ks);
+    } else {
         return CAD_ERR_UNSUPPORTED;
+    }
     return cad_after_launch();
 }
 

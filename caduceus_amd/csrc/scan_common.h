@@ -42,6 +42,22 @@ __device__ __forceinline__ f32x2 ld2(const float* p) {
     f32x2 r = {p[0], p[1]};
     return r;
 }
+// broadcast one half of a float2 to both halves: folds into op_sel / op_sel_hi of the consuming v_pk_* instruction,
+// so a per-item scalar pair such as (dt, dt*u) costs 2 VGPRs instead of 4 and no v_mov
+__device__ __forceinline__ f32x2 splat_lo(f32x2 v) {
+#ifdef CAD_EMU
+    return f2(v[0]);
+#else
+    return __builtin_shufflevector(v, v, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x2 splat_hi(f32x2 v) {
+#ifdef CAD_EMU
+    return f2(v[1]);
+#else
+    return __builtin_shufflevector(v, v, 1, 1);
+#endif
+}
 __device__ __forceinline__ f32x2 exp2_2(f32x2 v) { return f2(cad_exp2(v[0]), cad_exp2(v[1])); }
 __device__ __forceinline__ float dot2(f32x2 a, f32x2 b) { return a[0] * b[0] + a[1] * b[1]; }
 __device__ __forceinline__ f32x2 readlane2(f32x2 v, int l) { return f2(cad_readlane(v[0], l), cad_readlane(v[1], l)); }
@@ -100,11 +116,19 @@ struct __attribute__((aligned(16))) ScVec {
 };
 
 // raw (un-converted) load of SC_S logical positions [p0, p0+S); tail / unaligned rows fall back to scalar loads.
-template <typename T>
-__device__ __forceinline__ void sc_load_raw(const T* row, int64_t p0, int64_t L, int rev, bool vec_ok, ScVec<T>& out) {
-    if (vec_ok && p0 + SC_S <= L) {
-        const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
-        out = *(const ScVec<T>*)(row + l0);
+// VEC = true is the production instantiation: L % SC_S == 0 and 16-byte aligned rows, so a lane's segment is either
+// fully inside or fully outside [0, L) and is moved with one 16/32/64-byte access.  VEC = false handles any L / any
+// alignment element by element (small and ragged inputs).
+template <typename T, bool VEC>
+__device__ __forceinline__ void sc_load_raw(const T* row, int64_t p0, int64_t L, int rev, ScVec<T>& out) {
+    if constexpr (VEC) {
+        if (p0 < L) {
+            const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
+            out = *(const ScVec<T>*)(row + l0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SC_S; ++j) out.v[j] = from_f32<T>(0.f);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < SC_S; ++j) {
@@ -122,20 +146,22 @@ __device__ __forceinline__ void sc_unpack(const ScVec<T>& raw, int rev, float* o
 #pragma unroll
     for (int j = 0; j < SC_S; ++j) out[j] = to_f32(raw.v[rev ? (SC_S - 1 - j) : j]);
 }
-template <typename T>
-__device__ __forceinline__ void sc_load(const T* row, int64_t p0, int64_t L, int rev, bool vec_ok, float* out) {
+template <typename T, bool VEC>
+__device__ __forceinline__ void sc_load(const T* row, int64_t p0, int64_t L, int rev, float* out) {
     ScVec<T> raw;
-    sc_load_raw(row, p0, L, rev, vec_ok, raw);
+    sc_load_raw<T, VEC>(row, p0, L, rev, raw);
     sc_unpack(raw, rev, out);
 }
-template <typename T>
-__device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev, bool vec_ok, const float* v) {
-    if (vec_ok && p0 + SC_S <= L) {
-        const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
-        ScVec<T> tmp;
+template <typename T, bool VEC>
+__device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev, const float* v) {
+    if constexpr (VEC) {
+        if (p0 < L) {
+            const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
+            ScVec<T> tmp;
 #pragma unroll
-        for (int j = 0; j < SC_S; ++j) tmp.v[rev ? (SC_S - 1 - j) : j] = from_f32<T>(v[j]);
-        *(ScVec<T>*)(row + l0) = tmp;
+            for (int j = 0; j < SC_S; ++j) tmp.v[rev ? (SC_S - 1 - j) : j] = from_f32<T>(v[j]);
+            *(ScVec<T>*)(row + l0) = tmp;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < SC_S; ++j) {
@@ -158,9 +184,9 @@ struct StageRegs {
     StVec<T> s0, s1;
 };
 
-template <typename T>
+template <typename T, bool VEC>
 __device__ __forceinline__ void sc_stage_load(StageRegs<T>& r, const T* Bm, const T* Cm, int n0, int N, int64_t SB,
-                                              int64_t sb, int64_t base, int64_t L, int rev, bool vec_ok) {
+                                              int64_t sb, int64_t base, int64_t L, int rev) {
     const int t = threadIdx.x;
     const T* src = (t >> 7) ? Cm : Bm;
     const int64_t p0 = base + (int64_t)(t & 127) * SC_SV;
@@ -168,9 +194,14 @@ __device__ __forceinline__ void sc_stage_load(StageRegs<T>& r, const T* Bm, cons
     for (int s = 0; s < 2; ++s) {
         StVec<T>& dst = s ? r.s1 : r.s0;
         const T* row = src + ((int64_t)(n0 + s) * SB + sb) * L;
-        if (n0 + s < N && vec_ok && p0 + SC_SV <= L) {
-            const int64_t l0 = rev ? (L - p0 - SC_SV) : p0;
-            dst = *(const StVec<T>*)(row + l0);
+        if constexpr (VEC) {
+            if (n0 + s < N && p0 < L) {
+                const int64_t l0 = rev ? (L - p0 - SC_SV) : p0;
+                dst = *(const StVec<T>*)(row + l0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < SC_SV; ++j) dst.v[j] = from_f32<T>(0.f);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < SC_SV; ++j) {

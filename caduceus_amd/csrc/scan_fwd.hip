@@ -8,7 +8,7 @@ struct ScanFwdSets {
     cad_scan_args s[SC_MAXSETS];
 };
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE]
     const cad_scan_args& a = sets.s[blockIdx.z];
@@ -28,9 +28,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     T* o_row = (T*)a.out + row_off;
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
-    const bool vec_ok = ((L * sizeof(T)) % 16) == 0 &&
-                        (((uintptr_t)a.u | (uintptr_t)a.delta | (uintptr_t)a.z | (uintptr_t)a.out | (uintptr_t)a.Bm |
-                          (uintptr_t)a.Cm) % 16) == 0;
     const float Dv = a.D ? a.D[e] : 0.f;
     const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
@@ -39,30 +36,38 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     // flight (registers) while the current pair is computed.
     StageRegs<T> st;
     ScVec<T> u_raw, d_raw, z_raw;
-    sc_stage_load(st, Bm, Cm, 0, N, SB, sb, 0, L, rev, vec_ok);
-    sc_load_raw(u_row, (int64_t)lane * SC_S, L, rev, vec_ok, u_raw);
-    sc_load_raw(d_row, (int64_t)lane * SC_S, L, rev, vec_ok, d_raw);
+    sc_stage_load<T, VEC>(st, Bm, Cm, 0, N, SB, sb, 0, L, rev);
+    sc_load_raw<T, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
+    sc_load_raw<T, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
     sc_stage_store(st, smem, rev);
     __syncthreads();
 
     f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
+    // lane np holds (A[2np], A[2np+1]) * log2(e): read once, broadcast per pair with v_readlane (no memory access and
+    // therefore no s_waitcnt vmcnt(0) inside the pair loop, which would drain the tile prefetch)
+    f32x2 Areg = f2(0.f);
+    if (lane < NP) {
+        const int n0 = 2 * lane;
+        Areg = f2(a.A[e * N + n0] * CAD_LOG2E, (n0 + 1 < N) ? a.A[e * N + n0 + 1] * CAD_LOG2E : 0.f);
+    }
     int tix = 0;            // tiles consumed so far: tile tix lives in LDS buffer tix & 1
     for (int64_t c = 0; c < nchunks; ++c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float du[SC_S], dt[SC_S], y[SC_S];
+        f32x2 dd[SC_S];  // (dt, dt * u)
         sc_unpack(u_raw, rev, du);
         sc_unpack(d_raw, rev, dt);
-        if (z_row) sc_load_raw(z_row, p0, L, rev, vec_ok, z_raw);
+        if (z_row) sc_load_raw<T, VEC>(z_row, p0, L, rev, z_raw);
         if (c + 1 < nchunks) {
-            sc_load_raw(u_row, p0 + SC_CHUNK, L, rev, vec_ok, u_raw);
-            sc_load_raw(d_row, p0 + SC_CHUNK, L, rev, vec_ok, d_raw);
+            sc_load_raw<T, VEC>(u_row, p0 + SC_CHUNK, L, rev, u_raw);
+            sc_load_raw<T, VEC>(d_row, p0 + SC_CHUNK, L, rev, d_raw);
         }
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
-            dt[i] = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
+            const float dti = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
             y[i] = Dv * du[i];
-            du[i] *= dt[i];
+            dd[i] = f2(dti, dti * du[i]);
         }
         if (a.chunk_state && act && lane < NP) {
             float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
@@ -76,19 +81,18 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base + SC_CHUNK;
-                sc_stage_load(st, Bm, Cm, nn, N, SB, sb, nb, L, rev, vec_ok);
+                sc_stage_load<T, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
             }
             const float* tB = smem + buf * 2 * SC_TILE + lane * SC_ROW;
             const float* tC = tB + SC_TILE;
-            const int n0 = 2 * np;
-            const f32x2 A2 = f2(a.A[e * N + n0] * CAD_LOG2E, (n0 + 1 < N) ? a.A[e * N + n0 + 1] * CAD_LOG2E : 0.f);
+            const f32x2 A2 = readlane2(Areg, np);
             // (i) serial scan over the lane's items
             f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
             f32x2 ha[SC_S], hh[SC_S];
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
-                const f32x2 av = exp2_2(f2(dt[i]) * A2);
-                const f32x2 bv = f2(du[i]) * ld2(tB + 2 * i);
+                const f32x2 av = exp2_2(splat_lo(dd[i]) * A2);
+                const f32x2 bv = splat_hi(dd[i]) * ld2(tB + 2 * i);
                 acc_h = av * acc_h + bv;
                 acc_a = acc_a * av;
                 ha[i] = acc_a;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) y[i] *= zz[i] * cad_sigmoid(zz[i]);
         }
-        if (act) sc_store(o_row, p0, L, rev, vec_ok, y);
+        if (act) sc_store<T, VEC>(o_row, p0, L, rev, y);
     }
 }
 
@@ -145,15 +149,27 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
     }
     for (int i = nsets; i < SC_MAXSETS; ++i) ks.s[i] = sets[0];
     const cad_scan_args* a = &sets[0];
+    // fast path: whole lane segments + 16-byte aligned rows (any production shape); else the element-wise kernel
+    bool vec = (a->L % SC_S) == 0;
+    for (int i = 0; i < nsets; ++i)
+        vec = vec && (((uintptr_t)sets[i].u | (uintptr_t)sets[i].delta | (uintptr_t)sets[i].z | (uintptr_t)sets[i].out |
+                       (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm) % 16) == 0;
     CadProfScope prof(0, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const size_t shmem = (size_t)4 * SC_TILE * sizeof(float);
-    if (a->dtype == CAD_F32)
-        CAD_LAUNCH((scan_fwd_kernel<float>), grid, block, shmem, stream, ks);
-    else if (a->dtype == CAD_BF16)
-        CAD_LAUNCH((scan_fwd_kernel<bf16_t>), grid, block, shmem, stream, ks);
-    else
+    if (a->dtype == CAD_F32) {
+        if (vec)
+            CAD_LAUNCH((scan_fwd_kernel<float, true>), grid, block, shmem, stream, ks);
+        else
+            CAD_LAUNCH((scan_fwd_kernel<float, false>), grid, block, shmem, stream, ks);
+    } else if (a->dtype == CAD_BF16) {
+        if (vec)
+            CAD_LAUNCH((scan_fwd_kernel<bf16_t, true>), grid, block, shmem, stream, ks);
+        else
+            CAD_LAUNCH((scan_fwd_kernel<bf16_t, false>), grid, block, shmem, stream, ks);
+    } else {
         return CAD_ERR_UNSUPPORTED;
+    }
     return cad_after_launch();
 }
 
