@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--N", type=int, default=16)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only-scan", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -78,6 +79,9 @@ def main():
     t = timeit(bwd2, a.reps)
     res["scan_bwd2_ms"] = t
     res["scan_bwd2_GBps"] = 2 * (7 * E + 4 * N) * s * T / t / 1e6
+    if a.only_scan:
+        print(json.dumps({k: round(v, 3) for k, v in res.items()}))
+        return
     t = timeit(lambda: ops.causal_conv1d(u, w, cb, SB // 2 or SB, 0, 1), a.reps)
     res["conv_fwd_ms"] = t
     res["conv_fwd_GBps"] = 2 * E * s * T / t / 1e6
