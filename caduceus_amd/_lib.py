@@ -96,6 +96,7 @@ SYMBOLS = {
     "cad_scan_fwd_multi": (_i, [C.POINTER(ScanArgs), _i, _p]),
     "cad_scan_bwd_multi": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_reduce_partials": (_i, [_p, _i, _i64, _p, _i, _p]),
+    "cad_scan_bwd_partials": (_i, [_i]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_prof_enable": (_i, [_i]),
     "cad_prof_reset": (_i, []),

@@ -159,8 +159,6 @@ __device__ __forceinline__ float dpp_wave_shl1(float old, float v) {
     return lane < 63 ? r : old;
 }
 __device__ __forceinline__ float cad_readlane(float v, int l) { return emu_exchange(v, l); }
-__device__ __forceinline__ int cad_xcc_id() { return (int)((blockIdx.x * 5 + blockIdx.y * 3 + blockIdx.z) & 7); }
-__device__ __forceinline__ void cad_atomic_add_l2(float* p, float v) { *p += v; }
 #else
 #define CAD_DPP(old, v, ctrl, rmask)                                                                          \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)),              \
@@ -179,15 +177,6 @@ __device__ __forceinline__ float dpp_wave_shr1(float old, float v) { return CAD_
 __device__ __forceinline__ float dpp_wave_shl1(float old, float v) { return CAD_DPP(old, v, 0x130, 0xf); }
 __device__ __forceinline__ float cad_readlane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-// XCC (XCD) this wave runs on: HW_REG_XCC_ID (id 20), bits [3:0].  Used ONLY to pick which of 8 partial-sum
-// buffers receives this workgroup's L2-scope atomics: all CUs reporting the same id share one L2, so every value
-// in 0..7 is correct; the dispatcher's placement only affects speed.
-__device__ __forceinline__ int cad_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7); }
-// fp32 atomic add resolved in the XCD's L2 (no sc1 / fabric round trip).  Only valid on buffers that are private to
-// one XCD for the duration of the kernel (see cad_xcc_id); visible to later kernels after the end-of-kernel writeback.
-__device__ __forceinline__ void cad_atomic_add_l2(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 #endif
 

@@ -1,17 +1,18 @@
 // Selective SSM scan, backward (include/caduceus_hip.h, cad_scan_bwd / cad_scan_bwd_multi).
 // See scan_common.h for the decomposition.
 //
-// Per chunk (processed from the logical END of the row to its start, because the state gradient flows backwards)
-// and per state pair:
-//   1. recompute h over the chunk from the chunk-start state saved by the forward (serial + DPP wave scan);
+// Per 512-position chunk (processed from the logical END of the row to its start, because the state gradient flows
+// backwards) and per state pair:
+//   1. recompute h over the chunk from the running state saved by the forward (serial + DPP wave scan);
 //   2. reverse scan of  G_i = a_i * (c_i + G_{i+1}),  c_i = C_i * dy_i   (G_i = gradient flowing into h_{i-1});
 //      g_i = c_i + G_{i+1} is dL/dh_i;
 //   3. per item:  d(dt) += g*h_{i-1}*a*A + u*<g,B>,  dA += g*h_{i-1}*a*dt,  du += dt*<g,B>,
 //                 dB_i = g*dt*u,  dC_i = dy*h_i.
-// dB / dC must be summed over all E channels.  The SC_W channels of a workgroup are summed in LDS (ds_add_f32 into a
-// double-buffered tile), then the tile is added -- token-contiguous, coalesced -- to one of `n_partials` global fp32
-// buffers with fp32 atomics.  With n_partials == 8 the buffer is chosen by the XCD the workgroup runs on and the
-// atomics resolve in that XCD's L2 (no fabric round trip); cad_reduce_partials folds the 8 buffers afterwards.
+// dB / dC must be summed over all E channels.  Measured on MI355X (profiles/r01_scan_v2_pmc_summary.txt): a global
+// fp32 atomic costs one un-coalesced 64-byte HBM write per LANE, so no global atomics are used.  The SC_W_BWD channels of
+// a workgroup are summed in LDS (ds_add_f32 into a bank-conflict-free, double-buffered tile), the workgroup then
+// writes its partial sums with plain coalesced stores to slot blockIdx.x of a (E / SC_W_BWD)-deep partial buffer, and
+// cad_reduce_partials folds the slots (and converts to the activation dtype) in a second, purely streaming pass.
 #include "scan_common.h"
 
 namespace {
@@ -20,13 +21,22 @@ struct ScanBwdSets {
     cad_scan_bwd_args s[SC_MAXSETS];
 };
 
+#define SC_S SC_S_BWD
+#define SC_W SC_W_BWD
+#define SC_CHUNK (64 * SC_S)
+#define ACC_TILE (2 * SC_S * 64)  // floats per accumulator tile, layout [item i][state s][lane j]
+
+static_assert(SC_CHUNK == SC_STATE_STEP, "backward chunk = one saved-state slot");
+static_assert(64 * SC_W == 512, "the flush mapping below assumes 512 threads");
+
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum1(v[0]), wave_sum1(v[1])); }
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
-    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE] inputs, then [2 buffers][dB,dC][SC_TILE] accumulators
+    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][dB,dC][ACC_TILE] accumulators
+    constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     const cad_scan_bwd_args& a = sets.s[blockIdx.z];
-    float* acc = smem + 4 * SC_TILE;
+    float* acc = smem + 4 * TILE;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t sb = blockIdx.y;
@@ -51,23 +61,21 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const float keep = act ? 1.f : 0.f;  // padding waves (E % SC_W != 0) contribute nothing
     const int64_t part_stride = (int64_t)N * SB * L;
-    const bool l2_atomics = a.n_partials > 1;
-    const int part = l2_atomics ? (cad_xcc_id() % a.n_partials) : 0;
-    float* dBg = a.dB + (int64_t)part * part_stride;
-    float* dCg = a.dC + (int64_t)part * part_stride;
+    float* dBg = a.dB + (int64_t)blockIdx.x * part_stride;  // this workgroup's partial-sum slot
+    float* dCg = a.dC + (int64_t)blockIdx.x * part_stride;
 
-    for (int i = threadIdx.x; i < 4 * SC_TILE; i += blockDim.x) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * ACC_TILE; i += blockDim.x) acc[i] = 0.f;
 
-    StageRegs<T> st;
-    ScVec<T> u_raw, d_raw, g_raw, z_raw;
+    StageRegs<T, SC_SV(SC_S)> st;
+    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw;
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
-        sc_stage_load<T, VEC>(st, Bm, Cm, 0, N, SB, sb, base, L, rev);
-        sc_load_raw<T, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
-        sc_load_raw<T, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
-        sc_load_raw<T, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
-        if (z_row) sc_load_raw<T, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
-        sc_stage_store(st, smem, rev);
+        sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, 0, N, SB, sb, base, L, rev);
+        sc_load_raw<T, SC_S, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
+        sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
+        sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
+        if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
+        sc_stage_store<T, SC_S>(st, smem, rev);
     }
     __syncthreads();
 
@@ -85,40 +93,43 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     for (int64_t c = nchunks - 1; c >= 0; --c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
-        float uu[SC_S], dt[SC_S], dy[SC_S], ddt[SC_S], ddu[SC_S], y[SC_S];
+        float ddt[SC_S], ddu[SC_S], y[SC_S];
         f32x2 dd[SC_S], ee[SC_S];  // (dt, dt * u) and (dy, u)
-        sc_unpack(u_raw, rev, uu);
-        sc_unpack(d_raw, rev, dt);
-        sc_unpack(g_raw, rev, dy);
-        // chunk-start states of all pairs (saved by the forward): lane np fetches pair np, broadcast by v_readlane
+        {
+            float uu[SC_S], dt[SC_S], dy[SC_S];
+            sc_unpack<T, SC_S>(u_raw, rev, uu);
+            sc_unpack<T, SC_S>(d_raw, rev, dt);
+            sc_unpack<T, SC_S>(g_raw, rev, dy);
+            if (z_row) {
+                float zz[SC_S];
+                sc_unpack<T, SC_S>(z_raw, rev, zz);
+#pragma unroll
+                for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                const bool ok = p0 + i < L;
+                const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
+                const float dyi = ok ? dy[i] * keep : 0.f;
+                y[i] = Dv * uu[i];
+                ddt[i] = 0.f;
+                ddu[i] = dyi * Dv;
+                dDacc += dyi * uu[i];
+                dd[i] = f2(dti, dti * uu[i]);
+                ee[i] = f2(dyi, uu[i]);
+            }
+        }
+        // running states of all pairs at this chunk's start (saved by the forward): lane np fetches pair np
         f32x2 hin_reg = f2(0.f);
         if (lane < NP) {
             const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
             hin_reg = f2(stp[0], stp[1]);
         }
-        if (z_row) {
-            float zz[SC_S];
-            sc_unpack(z_raw, rev, zz);
-#pragma unroll
-            for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
-        }
         if (c > 0) {  // prefetch the item vectors of the next (earlier) chunk
-            sc_load_raw<T, VEC>(u_row, p0 - SC_CHUNK, L, rev, u_raw);
-            sc_load_raw<T, VEC>(d_row, p0 - SC_CHUNK, L, rev, d_raw);
-            sc_load_raw<T, VEC>(g_row, p0 - SC_CHUNK, L, rev, g_raw);
-            if (z_row) sc_load_raw<T, VEC>(z_row, p0 - SC_CHUNK, L, rev, z_raw);
-        }
-#pragma unroll
-        for (int i = 0; i < SC_S; ++i) {
-            const bool ok = p0 + i < L;
-            const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
-            const float dyi = ok ? dy[i] * keep : 0.f;
-            y[i] = Dv * uu[i];
-            ddt[i] = 0.f;
-            ddu[i] = dyi * Dv;
-            dDacc += dyi * uu[i];
-            dd[i] = f2(dti, dti * uu[i]);
-            ee[i] = f2(dyi, uu[i]);
+            sc_load_raw<T, SC_S, VEC>(u_row, p0 - SC_CHUNK, L, rev, u_raw);
+            sc_load_raw<T, SC_S, VEC>(d_row, p0 - SC_CHUNK, L, rev, d_raw);
+            sc_load_raw<T, SC_S, VEC>(g_row, p0 - SC_CHUNK, L, rev, g_raw);
+            if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0 - SC_CHUNK, L, rev, z_raw);
         }
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
@@ -126,12 +137,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
-                sc_stage_load<T, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
+                sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
             }
-            const float* tB = smem + buf * 2 * SC_TILE + lane * SC_ROW;
-            const float* tC = tB + SC_TILE;
-            float* aB = acc + buf * 2 * SC_TILE + lane * SC_ROW;
-            float* aC = aB + SC_TILE;
+            const float* tB = smem + buf * 2 * TILE + lane * ROW;
+            const float* tC = tB + TILE;
+            float* aB = acc + buf * 2 * ACC_TILE + lane;  // element (i, s) at aB[(2 i + s) * 64]: conflict-free
+            float* aC = aB + ACC_TILE;
             const int n0 = 2 * np;
             const f32x2 Av = readlane2(Areg, np);
             const f32x2 A2 = Av * f2(CAD_LOG2E);
@@ -187,46 +198,59 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * splat_lo(ee[i]);
-                atomicAdd(aB + 2 * i, dBv[0]);
-                atomicAdd(aB + 2 * i + 1, dBv[1]);
-                atomicAdd(aC + 2 * i, dCv[0]);
-                atomicAdd(aC + 2 * i + 1, dCv[1]);
+                atomicAdd(aB + (2 * i) * 64, dBv[0]);
+                atomicAdd(aB + (2 * i + 1) * 64, dBv[1]);
+                atomicAdd(aC + (2 * i) * 64, dCv[0]);
+                atomicAdd(aC + (2 * i + 1) * 64, dCv[1]);
             }
             dAp = wave_sum2(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
-            if (more) sc_stage_store(st, smem + (buf ^ 1) * 2 * SC_TILE, rev);
+            if (more) sc_stage_store<T, SC_S>(st, smem + (buf ^ 1) * 2 * TILE, rev);
             __syncthreads();  // every channel has added its dB/dC; the prefetched B/C tile is visible
-            // flush the channel-summed dB / dC tile of this pair (token-contiguous per thread), then clear it; the
-            // other accumulator buffer is the one the next pair adds into, so no second barrier is needed
+            // flush the channel-summed tile: thread t owns tensor t>>8, state (t>>7)&1 and 4 consecutive positions, i.e.
+            // one 16-byte store; then clear it.  The next pair adds into the other accumulator buffer, so one barrier
+            // per pair suffices.
             {
                 const int t = threadIdx.x;
-                float* tile = acc + buf * 2 * SC_TILE + (t >> 7) * SC_TILE;
-                float* gdst = (t >> 7) ? dCg : dBg;
-                const int tok = (t & 127) * SC_SV;
-                float* src = tile + (tok / SC_S) * SC_ROW + (tok % SC_S) * 2;
+                const int s = (t >> 7) & 1;
+                float* tile = acc + buf * 2 * ACC_TILE + (t >> 8) * ACC_TILE;
+                float* grow = ((t >> 8) ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
+                const int tok = (t & 127) * 4;
+                const int j = tok / SC_S, i0 = tok % SC_S;
+                float v[4];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (n0 + s < N) {
-                        float* grow = gdst + ((int64_t)(n0 + s) * SB + sb) * L;
-#pragma unroll
-                        for (int j = 0; j < SC_SV; ++j) {
-                            const int64_t p = base + tok + j;
-                            if (p < L) {
-                                if (l2_atomics)
-                                    cad_atomic_add_l2(grow + cad_phys(p, L, rev), src[2 * j + s]);
-                                else
-                                    atomicAdd(grow + cad_phys(p, L, rev), src[2 * j + s]);
+                for (int q = 0; q < 4; ++q) {
+                    float* src = tile + (2 * (i0 + q) + s) * 64 + j;
+                    v[q] = *src;
+                    *src = 0.f;
+                }
+                if (n0 + s < N) {
+                    const int64_t p = base + tok;
+                    if (VEC) {
+                        if (p < L) {
+                            typedef struct __attribute__((aligned(16))) {
+                                float f[4];
+                            } v4;
+                            v4 o;
+                            if (rev) {
+                                o.f[0] = v[3], o.f[1] = v[2], o.f[2] = v[1], o.f[3] = v[0];
+                                *(v4*)(grow + (L - p - 4)) = o;
+                            } else {
+                                o.f[0] = v[0], o.f[1] = v[1], o.f[2] = v[2], o.f[3] = v[3];
+                                *(v4*)(grow + p) = o;
                             }
                         }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (p + q < L) grow[cad_phys(p + q, L, rev)] = v[q];
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 2 * SC_SV; ++j) src[j] = 0.f;
             }
         }
-        // per-item outputs of this chunk (delta / z / dout are re-read: still L2-resident, keeps 48 VGPRs free)
+        // per-item outputs of this chunk (delta / z / dout are re-read: still L2-resident, keeps VGPRs free)
         float dl[SC_S];
-        sc_load<T, VEC>(d_row, p0, L, rev, dl);
+        sc_load<T, SC_S, VEC>(d_row, p0, L, rev, dl);
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const float xraw = dl[i] + bias;
@@ -235,22 +259,22 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             dbacc += ddt[i];
         }
         if (act) {
-            sc_store<T, VEC>(du_row, p0, L, rev, ddu);
-            sc_store<T, VEC>(dd_row, p0, L, rev, ddt);
+            sc_store<T, SC_S, VEC>(du_row, p0, L, rev, ddu);
+            sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
         }
         if (dz_row) {
             float zz[SC_S], go[SC_S];
-            sc_load<T, VEC>(z_row, p0, L, rev, zz);
-            sc_load<T, VEC>(g_row, p0, L, rev, go);
+            sc_load<T, SC_S, VEC>(z_row, p0, L, rev, zz);
+            sc_load<T, SC_S, VEC>(g_row, p0, L, rev, go);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const float sg = cad_sigmoid(zz[i]);
                 go[i] = go[i] * y[i] * sg * (1.f + zz[i] * (1.f - sg));
             }
-            if (act) sc_store<T, VEC>(dz_row, p0, L, rev, go);
+            if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, go);
         }
     }
-    // per-channel parameter gradients
+    // per-channel parameter gradients (E x N, E: a few device-scope atomics per wave, once per kernel)
     if (act && lane < NP) {
         const int n0 = 2 * lane;
         atomicAdd(a.dA + e * N + n0, dAacc[0]);
@@ -264,18 +288,34 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     }
 }
 
-// dst[i] = sum_k src[k * n + i]  (fp32 partial buffers -> dtype)
+// dst[i] = sum_k src[k * n + i]  (fp32 partial slots -> dtype); 4 elements per thread, 16-byte accesses
 template <typename T>
 __global__ void reduce_partials_kernel(const float* src, int nparts, int64_t n, T* dst) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float s = 0.f;
-        for (int k = 0; k < nparts; ++k) s += src[(int64_t)k * n + i];
-        dst[i] = from_f32<T>(s);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n && (n % 4) == 0) {
+            typedef struct __attribute__((aligned(16))) {
+                float f[4];
+            } v4;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int k = 0; k < nparts; ++k) {
+                const v4 x = *(const v4*)(src + (int64_t)k * n + i);
+                s0 += x.f[0], s1 += x.f[1], s2 += x.f[2], s3 += x.f[3];
+            }
+            dst[i] = from_f32<T>(s0), dst[i + 1] = from_f32<T>(s1), dst[i + 2] = from_f32<T>(s2), dst[i + 3] = from_f32<T>(s3);
+        } else {
+            for (int64_t q = i; q < n && q < i + 4; ++q) {
+                float s = 0.f;
+                for (int k = 0; k < nparts; ++k) s += src[(int64_t)k * n + q];
+                dst[q] = from_f32<T>(s);
+            }
+        }
     }
 }
 
 }  // namespace
+
+extern "C" int cad_scan_bwd_partials(int E) { return (E + SC_W - 1) / SC_W; }
 
 extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream) {
     CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= SC_MAXSETS);
@@ -287,7 +327,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
         CAD_CHECK_ARG((a->z == nullptr) == (a->dz == nullptr));
         CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
         CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
-        CAD_CHECK_ARG(a->n_partials == 1 || a->n_partials == 8);
+        CAD_CHECK_ARG(a->n_partials == cad_scan_bwd_partials(a->E));
         CAD_CHECK_ARG(a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L && a->N == sets[0].N &&
                       a->dtype == sets[0].dtype);
         ks.s[i] = *a;
@@ -298,10 +338,11 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     for (int i = 0; i < nsets; ++i)
         vec = vec && (((uintptr_t)sets[i].u | (uintptr_t)sets[i].delta | (uintptr_t)sets[i].z | (uintptr_t)sets[i].dout |
                        (uintptr_t)sets[i].du | (uintptr_t)sets[i].ddelta | (uintptr_t)sets[i].dz |
-                       (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm) % 16) == 0;
+                       (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm | (uintptr_t)sets[i].dB | (uintptr_t)sets[i].dC) %
+                      16) == 0;
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const size_t shmem = (size_t)8 * SC_TILE * sizeof(float);
+    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + 4 * ACC_TILE) * sizeof(float);
     if (a->dtype == CAD_F32) {
         if (vec)
             CAD_LAUNCH((scan_bwd_kernel<float, true>), grid, block, shmem, stream, ks);
@@ -322,8 +363,8 @@ extern "C" int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream) { return c
 
 extern "C" int cad_reduce_partials(const float* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream) {
     CAD_CHECK_ARG(src && dst && n_partials >= 1 && n > 0);
-    int64_t nb = (n + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    int64_t nb = (n / 4 + 255) / 256 + 1;
+    if (nb > 16384) nb = 16384;
     dim3 grid((unsigned)nb), block(256);
     if (dst_dtype == CAD_F32)
         CAD_LAUNCH((reduce_partials_kernel<float>), grid, block, 0, stream, src, n_partials, n, (float*)dst);

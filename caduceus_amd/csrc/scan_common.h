@@ -16,19 +16,30 @@
 #pragma once
 #include "cad_common.h"
 
-#ifndef SC_S
-#define SC_S 16                 // items per lane (8 or 16)
+// Tuning constants (overridable with -D for A/B builds).  The forward walks 1024-position chunks (16 items per lane);
+// the backward keeps ~2x more per-item state in registers and walks 512-position chunks (8 items per lane).  Both
+// index the saved running states by 512-position "half chunks" (SC_STATE_STEP).
+#ifndef SC_S_FWD
+#define SC_S_FWD 16
+#endif
+#ifndef SC_S_BWD
+#define SC_S_BWD 8
+#endif
+#ifndef SC_W_FWD
+#define SC_W_FWD 4              // waves (= channels) per forward workgroup
+#endif
+#ifndef SC_W_BWD
+#define SC_W_BWD 8              // waves (= channels) per backward workgroup: dB/dC are summed over them in LDS
 #endif
 #ifndef SC_OCC
 #define SC_OCC 2                // register budget: waves per SIMD the kernels are compiled for
 #endif
-#define SC_W 4                  // waves (= channels) per workgroup
-#define SC_CHUNK (64 * SC_S)    // logical positions per chunk step
-#define SC_ROW (2 * SC_S + 4)   // floats per lane row of a B/C tile (16 x float2 + 16 B pad: stride 144 B)
-#define SC_TILE (64 * SC_ROW)   // floats per tile
+#define SC_STATE_STEP 512
 #define SC_NMAX 64              // max d_state
 #define SC_MAXSETS 2
-#define SC_SV (SC_CHUNK / 128)   // tokens per staging thread (256 threads = 2 tensors x 128 threads x SC_SV tokens)
+#define SC_ROW(S) (2 * (S) + 4)        // floats per lane row of a B/C tile (S x float2 + 16 B pad -> conflict-free b128)
+#define SC_TILE(S) (64 * SC_ROW(S))    // floats per tile
+#define SC_SV(S) ((64 * (S)) / 128)    // tokens per staging thread (2 tensors x 128 threads x SC_SV tokens = one tile)
 
 __device__ __forceinline__ f32x2 f2(float a) {
     f32x2 r = {a, a};
@@ -110,30 +121,30 @@ __device__ __forceinline__ void wave_scan_rev(f32x2& A, f32x2& G, int lane) {
 }
 
 // ---- per-lane item vectors -------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int S>
 struct __attribute__((aligned(16))) ScVec {
-    T v[SC_S];
+    T v[S];
 };
 
 // raw (un-converted) load of SC_S logical positions [p0, p0+S); tail / unaligned rows fall back to scalar loads.
 // VEC = true is the production instantiation: L % SC_S == 0 and 16-byte aligned rows, so a lane's segment is either
 // fully inside or fully outside [0, L) and is moved with one 16/32/64-byte access.  VEC = false handles any L / any
 // alignment element by element (small and ragged inputs).
-template <typename T, bool VEC>
-__device__ __forceinline__ void sc_load_raw(const T* row, int64_t p0, int64_t L, int rev, ScVec<T>& out) {
+template <typename T, int S, bool VEC>
+__device__ __forceinline__ void sc_load_raw(const T* row, int64_t p0, int64_t L, int rev, ScVec<T, S>& out) {
     if constexpr (VEC) {
         if (p0 < L) {
-            const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
-            out = *(const ScVec<T>*)(row + l0);
+            const int64_t l0 = rev ? (L - p0 - S) : p0;
+            out = *(const ScVec<T, S>*)(row + l0);
         } else {
 #pragma unroll
-            for (int j = 0; j < SC_S; ++j) out.v[j] = from_f32<T>(0.f);
+            for (int j = 0; j < S; ++j) out.v[j] = from_f32<T>(0.f);
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < SC_S; ++j) {
+        for (int j = 0; j < S; ++j) {
             const int64_t p = p0 + j;
-            const int k = rev ? (SC_S - 1 - j) : j;  // keep the physical (memory-order) register layout of the fast path
+            const int k = rev ? (S - 1 - j) : j;  // keep the physical (memory-order) register layout of the fast path
             if (p < L)
                 out.v[k] = row[cad_phys(p, L, rev)];
             else
@@ -141,30 +152,30 @@ __device__ __forceinline__ void sc_load_raw(const T* row, int64_t p0, int64_t L,
         }
     }
 }
-template <typename T>
-__device__ __forceinline__ void sc_unpack(const ScVec<T>& raw, int rev, float* out) {
+template <typename T, int S>
+__device__ __forceinline__ void sc_unpack(const ScVec<T, S>& raw, int rev, float* out) {
 #pragma unroll
-    for (int j = 0; j < SC_S; ++j) out[j] = to_f32(raw.v[rev ? (SC_S - 1 - j) : j]);
+    for (int j = 0; j < S; ++j) out[j] = to_f32(raw.v[rev ? (S - 1 - j) : j]);
 }
-template <typename T, bool VEC>
+template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_load(const T* row, int64_t p0, int64_t L, int rev, float* out) {
-    ScVec<T> raw;
-    sc_load_raw<T, VEC>(row, p0, L, rev, raw);
-    sc_unpack(raw, rev, out);
+    ScVec<T, S> raw;
+    sc_load_raw<T, S, VEC>(row, p0, L, rev, raw);
+    sc_unpack<T, S>(raw, rev, out);
 }
-template <typename T, bool VEC>
+template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev, const float* v) {
     if constexpr (VEC) {
         if (p0 < L) {
-            const int64_t l0 = rev ? (L - p0 - SC_S) : p0;
-            ScVec<T> tmp;
+            const int64_t l0 = rev ? (L - p0 - S) : p0;
+            ScVec<T, S> tmp;
 #pragma unroll
-            for (int j = 0; j < SC_S; ++j) tmp.v[rev ? (SC_S - 1 - j) : j] = from_f32<T>(v[j]);
-            *(ScVec<T>*)(row + l0) = tmp;
+            for (int j = 0; j < S; ++j) tmp.v[rev ? (S - 1 - j) : j] = from_f32<T>(v[j]);
+            *(ScVec<T, S>*)(row + l0) = tmp;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < SC_S; ++j) {
+        for (int j = 0; j < S; ++j) {
             const int64_t p = p0 + j;
             if (p < L) row[cad_phys(p, L, rev)] = from_f32<T>(v[j]);
         }
@@ -172,41 +183,43 @@ __device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev,
 }
 
 // ---- B/C tile staging: global -> registers (prefetch) -> LDS ----------------------------------------------------------
-// Thread t of the 256-thread workgroup owns tensor (t >> 7) (0 = B, 1 = C) and the 8 logical positions
-// base + 8 * (t & 127) .. +8 of BOTH states of the pair.  Tile layout in LDS: [lane j][item i][state 0/1] fp32 with
-// row stride SC_ROW, i.e. the 16 floats a staging thread writes are contiguous (4 x ds_write_b128).
-template <typename T>
-struct __attribute__((aligned(sizeof(T) * SC_SV >= 16 ? 16 : 8))) StVec {
-    T v[SC_SV];
+// Threads 0..255 of the workgroup stage; thread t owns tensor (t >> 7) (0 = B, 1 = C) and the SV = S/2 logical
+// positions base + SV * (t & 127) .. of BOTH states of the pair.  Tile layout in LDS: [lane j][item i][state 0/1] fp32
+// with row stride SC_ROW(S), i.e. the 2*SV floats a staging thread writes are contiguous.
+template <typename T, int SV>
+struct __attribute__((aligned(sizeof(T) * SV >= 16 ? 16 : 8))) StVec {
+    T v[SV];
 };
-template <typename T>
+template <typename T, int SV>
 struct StageRegs {
-    StVec<T> s0, s1;
+    StVec<T, SV> s0, s1;
 };
 
-template <typename T, bool VEC>
-__device__ __forceinline__ void sc_stage_load(StageRegs<T>& r, const T* Bm, const T* Cm, int n0, int N, int64_t SB,
-                                              int64_t sb, int64_t base, int64_t L, int rev) {
+template <typename T, int S, bool VEC>
+__device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const T* Bm, const T* Cm, int n0, int N,
+                                              int64_t SB, int64_t sb, int64_t base, int64_t L, int rev) {
+    constexpr int SV = SC_SV(S);
     const int t = threadIdx.x;
+    if (t >= 256) return;
     const T* src = (t >> 7) ? Cm : Bm;
-    const int64_t p0 = base + (int64_t)(t & 127) * SC_SV;
+    const int64_t p0 = base + (int64_t)(t & 127) * SV;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        StVec<T>& dst = s ? r.s1 : r.s0;
+        StVec<T, SV>& dst = s ? r.s1 : r.s0;
         const T* row = src + ((int64_t)(n0 + s) * SB + sb) * L;
         if constexpr (VEC) {
             if (n0 + s < N && p0 < L) {
-                const int64_t l0 = rev ? (L - p0 - SC_SV) : p0;
-                dst = *(const StVec<T>*)(row + l0);
+                const int64_t l0 = rev ? (L - p0 - SV) : p0;
+                dst = *(const StVec<T, SV>*)(row + l0);
             } else {
 #pragma unroll
-                for (int j = 0; j < SC_SV; ++j) dst.v[j] = from_f32<T>(0.f);
+                for (int j = 0; j < SV; ++j) dst.v[j] = from_f32<T>(0.f);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < SC_SV; ++j) {
+            for (int j = 0; j < SV; ++j) {
                 const int64_t p = p0 + j;
-                const int k = rev ? (SC_SV - 1 - j) : j;
+                const int k = rev ? (SV - 1 - j) : j;
                 if (n0 + s < N && p < L)
                     dst.v[k] = row[cad_phys(p, L, rev)];
                 else
@@ -216,15 +229,18 @@ __device__ __forceinline__ void sc_stage_load(StageRegs<T>& r, const T* Bm, cons
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void sc_stage_store(const StageRegs<T>& r, float* tiles /* B tile, C tile follows */, int rev) {
+template <typename T, int S>
+__device__ __forceinline__ void sc_stage_store(const StageRegs<T, SC_SV(S)>& r, float* tiles /* B tile, C tile follows */,
+                                               int rev) {
+    constexpr int SV = SC_SV(S);
     const int t = threadIdx.x;
-    float* tile = tiles + (t >> 7) * SC_TILE;
-    const int tok = (t & 127) * SC_SV;  // position inside the chunk
-    float* dst = tile + (tok / SC_S) * SC_ROW + (tok % SC_S) * 2;
+    if (t >= 256) return;
+    float* tile = tiles + (t >> 7) * SC_TILE(S);
+    const int tok = (t & 127) * SV;  // position inside the chunk
+    float* dst = tile + (tok / S) * SC_ROW(S) + (tok % S) * 2;
 #pragma unroll
-    for (int j = 0; j < SC_SV; ++j) {
-        const int k = rev ? (SC_SV - 1 - j) : j;
+    for (int j = 0; j < SV; ++j) {
+        const int k = rev ? (SV - 1 - j) : j;
         dst[2 * j] = to_f32(r.s0.v[k]);
         dst[2 * j + 1] = to_f32(r.s1.v[k]);
     }

@@ -8,9 +8,14 @@ struct ScanFwdSets {
     cad_scan_args s[SC_MAXSETS];
 };
 
+#define SC_S SC_S_FWD
+#define SC_W SC_W_FWD
+#define SC_CHUNK (64 * SC_S)
+
 template <typename T, bool VEC>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE]
+    constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     const cad_scan_args& a = sets.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -31,15 +36,16 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     const float Dv = a.D ? a.D[e] : 0.f;
     const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
+    const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
 
     // software pipeline: the B/C tile of the NEXT (chunk, pair) and the u/delta/z vectors of the NEXT chunk are in
     // flight (registers) while the current pair is computed.
-    StageRegs<T> st;
-    ScVec<T> u_raw, d_raw, z_raw;
-    sc_stage_load<T, VEC>(st, Bm, Cm, 0, N, SB, sb, 0, L, rev);
-    sc_load_raw<T, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
-    sc_load_raw<T, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
-    sc_stage_store(st, smem, rev);
+    StageRegs<T, SC_SV(SC_S)> st;
+    ScVec<T, SC_S> u_raw, d_raw, z_raw;
+    sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, 0, N, SB, sb, 0, L, rev);
+    sc_load_raw<T, SC_S, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
+    sc_load_raw<T, SC_S, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
+    sc_stage_store<T, SC_S>(st, smem, rev);
     __syncthreads();
 
     f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
@@ -56,12 +62,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float du[SC_S], dt[SC_S], y[SC_S];
         f32x2 dd[SC_S];  // (dt, dt * u)
-        sc_unpack(u_raw, rev, du);
-        sc_unpack(d_raw, rev, dt);
-        if (z_row) sc_load_raw<T, VEC>(z_row, p0, L, rev, z_raw);
+        sc_unpack<T, SC_S>(u_raw, rev, du);
+        sc_unpack<T, SC_S>(d_raw, rev, dt);
+        if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
         if (c + 1 < nchunks) {
-            sc_load_raw<T, VEC>(u_row, p0 + SC_CHUNK, L, rev, u_raw);
-            sc_load_raw<T, VEC>(d_row, p0 + SC_CHUNK, L, rev, d_raw);
+            sc_load_raw<T, SC_S, VEC>(u_row, p0 + SC_CHUNK, L, rev, u_raw);
+            sc_load_raw<T, SC_S, VEC>(d_row, p0 + SC_CHUNK, L, rev, d_raw);
         }
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
@@ -69,10 +75,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             y[i] = Dv * du[i];
             dd[i] = f2(dti, dti * du[i]);
         }
-        if (a.chunk_state && act && lane < NP) {
-            float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
-            stp[0] = carry[0];
-            stp[1] = carry[1];
+        // running state at this chunk's start (state slot 2c); the mid-chunk state (slot 2c+1) is written per pair
+        float* st_base = a.chunk_state ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + 2 * c) * NP * 2 : nullptr;
+        if (st_base && act && lane < NP) {
+            st_base[lane * 2] = carry[0];
+            st_base[lane * 2 + 1] = carry[1];
         }
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
@@ -81,10 +88,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base + SC_CHUNK;
-                sc_stage_load<T, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
+                sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
             }
-            const float* tB = smem + buf * 2 * SC_TILE + lane * SC_ROW;
-            const float* tC = tB + SC_TILE;
+            const float* tB = smem + buf * 2 * TILE + lane * ROW;
+            const float* tC = tB + TILE;
             const f32x2 A2 = readlane2(Areg, np);
             // (i) serial scan over the lane's items
             f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
@@ -106,6 +113,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             // (iii) carry in / out
             const f32x2 hin = readlane2(carry, np);
             const f32x2 h0 = ea * hin + eh;
+            // state entering lane 32 = state at logical position base + 512: the backward's half-chunk start
+            if (st_base && act && base + SC_STATE_STEP < L) {
+                const f32x2 mid = readlane2(h0, SC_STATE_STEP / SC_S);
+                if (lane == 0) {
+                    st_base[(NP + np) * 2] = mid[0];
+                    st_base[(NP + np) * 2 + 1] = mid[1];
+                }
+            }
             const f32x2 newc = readlane2(PA * hin + PH, 63);
             if (lane == np) carry = newc;
 #pragma unroll
@@ -113,26 +128,28 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
                 const f32x2 h = ha[i] * h0 + hh[i];
                 y[i] += dot2(ld2(tC + 2 * i), h);
             }
-            if (more) sc_stage_store(st, smem + (buf ^ 1) * 2 * SC_TILE, rev);
+            if (more) sc_stage_store<T, SC_S>(st, smem + (buf ^ 1) * 2 * TILE, rev);
             __syncthreads();
         }
         if (z_row) {
             float zz[SC_S];
-            sc_unpack(z_raw, rev, zz);
+            sc_unpack<T, SC_S>(z_raw, rev, zz);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) y[i] *= zz[i] * cad_sigmoid(zz[i]);
         }
-        if (act) sc_store<T, VEC>(o_row, p0, L, rev, y);
+        if (act) sc_store<T, SC_S, VEC>(o_row, p0, L, rev, y);
     }
 }
 
 }  // namespace
 
+static_assert(SC_CHUNK == 2 * SC_STATE_STEP, "forward chunk = two state slots");
+
 extern "C" int64_t cad_scan_chunk_len(void) { return SC_CHUNK; }
 
 extern "C" int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N) {
-    const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
-    return (int64_t)E * SB * nchunks * ((N + 1) / 2) * 2;
+    const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
+    return (int64_t)E * SB * (nslots + 1) * ((N + 1) / 2) * 2;
 }
 
 extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream) {
@@ -156,7 +173,7 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
                        (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm) % 16) == 0;
     CadProfScope prof(0, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const size_t shmem = (size_t)4 * SC_TILE * sizeof(float);
+    const size_t shmem = (size_t)4 * SC_TILE(SC_S) * sizeof(float);
     if (a->dtype == CAD_F32) {
         if (vec)
             CAD_LAUNCH((scan_fwd_kernel<float, true>), grid, block, shmem, stream, ks);

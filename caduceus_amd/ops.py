@@ -8,7 +8,6 @@ memory, streams and the autograd graph; all arithmetic of these ops happens in t
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -162,9 +161,6 @@ def causal_conv1d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
 # ------------------------------------------------------------------------------------------------------------------
 # selective scan
 # ------------------------------------------------------------------------------------------------------------------
-SCAN_PARTIALS = int(os.environ.get("CADUCEUS_AMD_SCAN_PARTIALS", "8"))  # 8: per-XCD L2 atomics for dB/dC; 1: device scope
-
-
 class _ScanMulti(torch.autograd.Function):
     """1 or 2 parameter sets (same shapes, shared gate z) in one launch.  Tensor args per set:
     u, delta, A, Bm, Cm, D, delta_bias."""
@@ -209,7 +205,6 @@ class _ScanMulti(torch.autograd.Function):
         lib = L.get_lib()
         args = (L.ScanBwdArgs * nsets)()
         keep, res = [], []
-        npart = SCAN_PARTIALS
         for i in range(nsets):
             u, delta, Af, Bm, Cm, Df, bf, state = flat[8 * i:8 * i + 8]
             E, SB, Lq = u.shape
@@ -218,7 +213,8 @@ class _ScanMulti(torch.autograd.Function):
             du, ddelta = torch.empty_like(u), torch.empty_like(u)
             dz = None if z is None else torch.empty_like(u)
             dA, dD, dbias = torch.zeros_like(Af), torch.zeros_like(Df), torch.zeros_like(bf)
-            dBC = torch.zeros((2, npart, N, SB, Lq), dtype=torch.float32, device=u.device)
+            npart = lib.cad_scan_bwd_partials(E)  # one fp32 partial-sum slot per workgroup (written, not accumulated)
+            dBC = torch.empty((2, npart, N, SB, Lq), dtype=torch.float32, device=u.device)
             stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dBC, dD, dbias)
             rl, rh = dirs[i]
             args[i] = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
@@ -234,6 +230,7 @@ class _ScanMulti(torch.autograd.Function):
             du, ddelta, dA, dBC, dD, dbias, dz = res[i]
             u = flat[8 * i]
             n = dBC[0, 0].numel()
+            npart = dBC.shape[1]
             dB, dC = torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device), \
                 torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device)
             for src, dst in ((dBC[0], dB), (dBC[1], dC)):

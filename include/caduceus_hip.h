@@ -191,10 +191,10 @@ int cad_scan_fwd(const cad_scan_args* a, void* stream);
 int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream);
 int64_t cad_scan_chunk_len(void);
 int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
-/* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E) are ACCUMULATED with fp32 atomics
- * (caller zeroes).  dB, dC: n_partials fp32 buffers of (N,SB,L) each, ACCUMULATED (caller zeroes; summation order over
- * channels is not deterministic).  n_partials = 1: one buffer, device-scope atomics.  n_partials = 8: one buffer per
- * XCD, atomics resolved in that XCD's L2; fold them with cad_reduce_partials. */
+/* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E) are ACCUMULATED with a few fp32
+ * atomics per channel (caller zeroes).  dB, dC: n_partials = cad_scan_bwd_partials(E) fp32 slots of (N,SB,L) each;
+ * slot k is WRITTEN (plain coalesced stores, no atomics, no zeroing needed) with the sum over the channels of workgroup
+ * k; cad_reduce_partials folds the slots into the final (N,SB,L) gradient.  chunk_state: as written by the forward. */
 typedef struct {
     const void* u;
     const void* delta;
@@ -222,6 +222,7 @@ typedef struct {
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
+int cad_scan_bwd_partials(int E);
 /* dst[i] = sum_k src[k*n + i], k < n_partials; dst in dst_dtype (fp32 or bf16). */
 int cad_reduce_partials(const float* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream);
 
