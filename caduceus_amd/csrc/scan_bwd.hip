@@ -8,11 +8,14 @@
 //      g_i = c_i + G_{i+1} is dL/dh_i;
 //   3. per item:  d(dt) += g*h_{i-1}*a*A + u*<g,B>,  dA += g*h_{i-1}*a*dt,  du += dt*<g,B>,
 //                 dB_i = g*dt*u,  dC_i = dy*h_i.
-// dB / dC must be summed over all E channels.  Measured on MI355X (profiles/r01_scan_v2_pmc_summary.txt): a global
-// fp32 atomic costs one un-coalesced 64-byte HBM write per LANE, so no global atomics are used.  The SC_W_BWD channels of
-// a workgroup are summed in LDS (ds_add_f32 into a bank-conflict-free, double-buffered tile), the workgroup then
-// writes its partial sums with plain coalesced stores to slot blockIdx.x of a (E / SC_W_BWD)-deep partial buffer, and
-// cad_reduce_partials folds the slots (and converts to the activation dtype) in a second, purely streaming pass.
+// dB / dC must be summed over all E channels.  Measured on MI355X (profiles/r01_scan_v2_pmc_summary.txt and the
+// microbenchmarks next to it): a global fp32 atomic costs one un-coalesced 64-byte HBM write per LANE, and an LDS
+// ds_add_f32 retires only ~1 lane every 3 cycles (~200 cycles per wave instruction) -- so NO atomics of either kind are
+// used.  Each of the SC_W_BWD waves (channels) of a workgroup writes its dB/dC contributions with plain ds_write_b64
+// into its own region of a double-buffered LDS slab; after the (single) barrier of the pair the 512 threads sum the
+// SC_W_BWD regions and store the workgroup's partial sums with coalesced 16-byte stores to slot blockIdx.x of a
+// (E / SC_W_BWD)-deep partial buffer; cad_reduce_partials folds the slots (and converts to the activation dtype) in a
+// second, purely streaming pass.
 #include "scan_common.h"
 
 namespace {
@@ -24,16 +27,17 @@ struct ScanBwdSets {
 #define SC_S SC_S_BWD
 #define SC_W SC_W_BWD
 #define SC_CHUNK (64 * SC_S)
-#define ACC_TILE (2 * SC_S * 64)  // floats per accumulator tile, layout [item i][state s][lane j]
+#define ACC_TILE (SC_S * 64 * 2)        // floats per (wave, tensor) region, layout [item i][lane j][state s]
+#define ACC_BUF (SC_W * 2 * ACC_TILE)  // floats per buffer: [wave][dB,dC][ACC_TILE]
 
 static_assert(SC_CHUNK == SC_STATE_STEP, "backward chunk = one saved-state slot");
 static_assert(64 * SC_W == 512, "the flush mapping below assumes 512 threads");
 
-__device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum1(v[0]), wave_sum1(v[1])); }
+__device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1])); }
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
-    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][dB,dC][ACC_TILE] accumulators
+    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][wave][dB,dC][ACC_TILE] contributions
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     const cad_scan_bwd_args& a = sets.s[blockIdx.z];
     float* acc = smem + 4 * TILE;
@@ -63,8 +67,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const int64_t part_stride = (int64_t)N * SB * L;
     float* dBg = a.dB + (int64_t)blockIdx.x * part_stride;  // this workgroup's partial-sum slot
     float* dCg = a.dC + (int64_t)blockIdx.x * part_stride;
-
-    for (int i = threadIdx.x; i < 4 * ACC_TILE; i += blockDim.x) acc[i] = 0.f;
 
     StageRegs<T, SC_SV(SC_S)> st;
     ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
-            float* aB = acc + buf * 2 * ACC_TILE + lane;  // element (i, s) at aB[(2 i + s) * 64]: conflict-free
+            float* aB = acc + buf * ACC_BUF + wave * 2 * ACC_TILE + lane * 2;  // (i, s) at aB[i * 128 + s]: 8-byte stride
             float* aC = aB + ACC_TILE;
             const int n0 = 2 * np;
             const f32x2 Av = readlane2(Areg, np);
@@ -198,31 +200,30 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * splat_lo(ee[i]);
-                atomicAdd(aB + (2 * i) * 64, dBv[0]);
-                atomicAdd(aB + (2 * i + 1) * 64, dBv[1]);
-                atomicAdd(aC + (2 * i) * 64, dCv[0]);
-                atomicAdd(aC + (2 * i + 1) * 64, dCv[1]);
+                *(f32x2*)(aB + i * 128) = dBv;  // ds_write_b64, conflict-free
+                *(f32x2*)(aC + i * 128) = dCv;
             }
             dAp = wave_sum2(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
             if (more) sc_stage_store<T, SC_S>(st, smem + (buf ^ 1) * 2 * TILE, rev);
-            __syncthreads();  // every channel has added its dB/dC; the prefetched B/C tile is visible
-            // flush the channel-summed tile: thread t owns tensor t>>8, state (t>>7)&1 and 4 consecutive positions, i.e.
-            // one 16-byte store; then clear it.  The next pair adds into the other accumulator buffer, so one barrier
-            // per pair suffices.
+            __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
+            // sum the SC_W regions and flush: thread t owns tensor t>>8, state (t>>7)&1 and 4 consecutive positions, i.e.
+            // one 16-byte store.  The next pair writes the other slab buffer, so one barrier per pair suffices.
             {
                 const int t = threadIdx.x;
                 const int s = (t >> 7) & 1;
-                float* tile = acc + buf * 2 * ACC_TILE + (t >> 8) * ACC_TILE;
+                const float* tile = acc + buf * ACC_BUF + (t >> 8) * ACC_TILE;
                 float* grow = ((t >> 8) ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
                 const int tok = (t & 127) * 4;
                 const int j = tok / SC_S, i0 = tok % SC_S;
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float* src = tile + (2 * (i0 + q) + s) * 64 + j;
-                    v[q] = *src;
-                    *src = 0.f;
+                    const float* src = tile + (i0 + q) * 128 + j * 2 + s;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < SC_W; ++w) sum += src[w * 2 * ACC_TILE];
+                    v[q] = sum;
                 }
                 if (n0 + s < N) {
                     const int64_t p = base + tok;
@@ -342,7 +343,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
                       16) == 0;
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + 4 * ACC_TILE) * sizeof(float);
+    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + 2 * ACC_BUF) * sizeof(float);
     if (a->dtype == CAD_F32) {
         if (vec)
             CAD_LAUNCH((scan_bwd_kernel<float, true>), grid, block, shmem, stream, ks);

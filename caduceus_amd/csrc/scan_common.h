@@ -78,6 +78,15 @@ __device__ __forceinline__ float wave_sum1(float v) {
     return v;
 }
 
+// wave-wide sum, result valid in EVERY lane: DPP row reduction (4 steps) + 4 v_readlane, no LDS traffic
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_row_shr<1>(0.f, v);
+    v += dpp_row_shr<2>(0.f, v);
+    v += dpp_row_shr<4>(0.f, v);
+    v += dpp_row_shr<8>(0.f, v);  // lane 15 of each row now holds its row total
+    return (cad_readlane(v, 15) + cad_readlane(v, 31)) + (cad_readlane(v, 47) + cad_readlane(v, 63));
+}
+
 // One Kogge-Stone step of the affine-map scan: (A, H) <- (A, H) o (ua, uh) where (ua, uh) is the partner's map
 // (identity where the DPP pattern has no source):  x -> A * (ua * x + uh) + H.
 #define SC_COMBINE(A, H, UA0, UA1, UH0, UH1) \
