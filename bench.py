@@ -158,8 +158,9 @@ def main():
         tokens = args.batch * args.seqlen * world * args.steps
         E, N = 2 * args.d_model, SSM_CFG["d_state"]
         s = 2 if args.dtype == "bf16" else 4
-        rows_tokens = 2 * args.batch * args.seqlen  # both strands go through every scan launch
-        alg = {"scan_fwd": (4 * E + 2 * N) * s * rows_tokens, "scan_bwd": (7 * E + 4 * N) * s * rows_tokens}
+        # one launch = both strands x both parameter sets (mamba_fwd, mamba_rev) of a layer = 4 Mamba invocations/token
+        inv_tokens = 4 * args.batch * args.seqlen
+        alg = {"scan_fwd": (4 * E + 2 * N) * s * inv_tokens, "scan_bwd": (7 * E + 4 * N) * s * inv_tokens}
         kinds = {}
         for k in ("scan_fwd", "scan_bwd"):
             ms, n = prof[k]
