@@ -159,6 +159,7 @@ __device__ __forceinline__ float dpp_wave_shl1(float old, float v) {
     return lane < 63 ? r : old;
 }
 __device__ __forceinline__ float cad_readlane(float v, int l) { return emu_exchange(v, l); }
+__device__ __forceinline__ int cad_uniform(int v) { return v; }
 #else
 #define CAD_DPP(old, v, ctrl, rmask)                                                                          \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)),              \
@@ -178,6 +179,9 @@ __device__ __forceinline__ float dpp_wave_shl1(float old, float v) { return CAD_
 __device__ __forceinline__ float cad_readlane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+// tell the compiler a value is wave-uniform (e.g. the wave index threadIdx.x >> 6): everything derived from it -- row
+// base pointers, channel parameters -- then lives in SGPRs instead of VGPRs
+__device__ __forceinline__ int cad_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
 // ---- direction / index maps ----------------------------------------------------------------------------------

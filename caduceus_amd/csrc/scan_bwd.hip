@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const cad_scan_bwd_args& a = sets.s[blockIdx.z];
     float* acc = smem + 4 * TILE;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = cad_uniform(threadIdx.x >> 6);
     const int64_t sb = blockIdx.y;
     const int e_raw = blockIdx.x * SC_W + wave;
     const bool act = e_raw < a.E;

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     const cad_scan_args& a = sets.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = cad_uniform(threadIdx.x >> 6);
     const int64_t sb = blockIdx.y;
     const int e_raw = blockIdx.x * SC_W + wave;
     const bool act = e_raw < a.E;
