@@ -8,9 +8,10 @@ from .configuration_caduceus import CaduceusConfig
 from .modeling_caduceus import (BiMambaWrapper, Caduceus, CaduceusForMaskedLM, CaduceusForSequenceClassification,
                                 CaduceusMixerModel, create_block)
 from .modeling_rcps import RCPSAddNormWrapper, RCPSEmbedding, RCPSLMHead, RCPSMambaBlock, RCPSWrapper
+from .tokenization_caduceus import CaduceusTokenizer
 
 __all__ = ["CaduceusConfig", "Caduceus", "CaduceusForMaskedLM", "CaduceusForSequenceClassification",
-           "CaduceusMixerModel", "BiMambaWrapper", "create_block", "RCPSEmbedding", "RCPSWrapper",
+           "CaduceusTokenizer", "CaduceusMixerModel", "BiMambaWrapper", "create_block", "RCPSEmbedding", "RCPSWrapper",
            "RCPSAddNormWrapper", "RCPSMambaBlock", "RCPSLMHead", "register_auto_classes"]
 
 

@@ -117,3 +117,18 @@ def test_forward_signature_has_no_state_param():
     assert "state" not in params
     assert list(params)[1:] == ["input_ids", "inputs_embeds", "labels", "loss_weights", "output_hidden_states",
                                 "return_dict"]
+
+
+def test_tokenizer_ids_and_complement_map():
+    """SURVEY.md Appendix A (tokenization_caduceus.py:49-66)."""
+    from caduceus_amd import CaduceusTokenizer
+    tok = CaduceusTokenizer(model_max_length=64)
+    assert tok.vocab_size == 12
+    assert tok.get_vocab() == {"[CLS]": 0, "[SEP]": 1, "[BOS]": 2, "[MASK]": 3, "[PAD]": 4, "[RESERVED]": 5, "[UNK]": 6,
+                               "A": 7, "C": 8, "G": 9, "T": 10, "N": 11}
+    assert tok.complement_map == {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 6, 7: 10, 8: 9, 9: 8, 10: 7, 11: 11}
+    ids = tok("acgtnX", add_special_tokens=False)["input_ids"]
+    assert ids == [7, 8, 9, 10, 11, 6]
+    assert tok.padding_side == "left" and tok.pad_token_id == 4 and tok.mask_token_id == 3
+    assert tok.build_inputs_with_special_tokens([7, 8]) == [7, 8, 1]
+    CaduceusTokenizer(model_max_length=16, add_special_tokens=False)  # the reference's constructor call (genomics.py:108-111)
