@@ -55,7 +55,7 @@ class Conv1dArgs(C.Structure):
 class Conv1dBwdArgs(C.Structure):
     _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("dout", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
                 ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i),
-                ("dtype", _i)]
+                ("dtype", _i), ("accumulate", _i)]
 
 
 class ScanArgs(C.Structure):

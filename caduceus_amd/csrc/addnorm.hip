@@ -155,6 +155,202 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_kernel(cad_add_nor
     }
 }
 
+
+// ---- vectorised variants (D % 4 == 0): a lane owns 4 consecutive channels per 256-channel step --------------------
+// 8-byte (bf16) / 16-byte (fp32) accesses; with swap_flip the 4 outputs land, reversed, on 4 consecutive channels of
+// the other strand, so they are still one vector store.
+#define ANV_KMAX 4  // D <= 1024
+
+template <typename T>
+__device__ __forceinline__ void ld4(const T* p, float* o);
+template <>
+__device__ __forceinline__ void ld4<float>(const float* p, float* o) {
+    struct __attribute__((aligned(16))) V { float f[4]; };
+    const V t = *(const V*)p;
+    o[0] = t.f[0], o[1] = t.f[1], o[2] = t.f[2], o[3] = t.f[3];
+}
+template <>
+__device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float* o) {
+    struct __attribute__((aligned(8))) V { uint32_t w[2]; };
+    const V t = *(const V*)p;
+    o[0] = cad_bits2f(t.w[0] << 16), o[1] = cad_bits2f(t.w[0] & 0xffff0000u);
+    o[2] = cad_bits2f(t.w[1] << 16), o[3] = cad_bits2f(t.w[1] & 0xffff0000u);
+}
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add_norm_args a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t R = a.rows_per_strand;
+    const int64_t nrows = R * a.n_strands;
+    const int D = a.D;
+    const TX* x = (const TX*)a.x;
+    TY* y = (TY*)a.y;
+    const float invD = 1.0f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * AN_WAVES + wave; row < nrows; row += (int64_t)gridDim.x * AN_WAVES) {
+        const int s = (int)(row / R);
+        const int64_t r = row - (int64_t)s * R;
+        const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
+        float v[ANV_KMAX][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < ANV_KMAX; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < D) {
+                ld4<TX>(x + row * D + c, v[k]);
+                if (a.residual_in) {
+                    float t[4];
+                    ld4<float>(a.residual_in + row * D + c, t);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[k][q] += t[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s1 += v[k][q];
+                    s2 += v[k][q] * v[k][q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[k][q] = 0.f;
+            }
+        }
+        float mean = 0.f, rstd;
+        if (a.is_rms) {
+            s2 = wave_sum(s2);
+            rstd = cad_rsqrt(s2 * invD + a.eps);
+        } else {
+            s1 = wave_sum(s1);
+            mean = s1 * invD;
+            float qq = 0.f;
+#pragma unroll
+            for (int k = 0; k < ANV_KMAX; ++k) {
+                const int c = (lane + 64 * k) * 4;
+                if (c < D) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float d = v[k][q] - mean;
+                        qq += d * d;
+                    }
+                }
+            }
+            qq = wave_sum(qq);
+            rstd = cad_rsqrt(qq * invD + a.eps);
+        }
+        if (lane == 0) {
+            a.rstd[row] = rstd;
+            if (a.mean) a.mean[row] = mean;
+        }
+#pragma unroll
+        for (int k = 0; k < ANV_KMAX; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < D) {
+                const int oc = a.swap_flip ? (D - 4 - c) : c;  // first of the 4 output channels
+                float w[4], o[4], ro[4];
+                ld4<float>(a.weight + oc, w);
+                float b[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) ld4<float>(a.bias + oc, b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int qi = a.swap_flip ? (3 - q) : q;  // input element feeding output element q
+                    o[q] = (v[k][qi] - mean) * rstd * w[q] + b[q];
+                    ro[q] = v[k][qi];
+                }
+                cad_cvt_store<TY, 4>(y + orow * D + oc, o);
+                if (a.residual_out) cad_cvt_store<float, 4>(a.residual_out + orow * D + oc, ro);
+            }
+        }
+    }
+}
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_vec_kernel(cad_add_norm_bwd_args a) {
+    __shared__ float red[AN_WAVES][64 * ANV_KMAX * 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t R = a.rows_per_strand;
+    const int64_t nrows = R * a.n_strands;
+    const int D = a.D;
+    const TY* dy = (const TY*)a.dy;
+    TX* dx = (TX*)a.dx;
+    const float invD = 1.0f / (float)D;
+    float dw[ANV_KMAX][4], db[ANV_KMAX][4];  // indexed by OUTPUT channel oc + q
+#pragma unroll
+    for (int k = 0; k < ANV_KMAX; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dw[k][q] = db[k][q] = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * AN_WAVES + wave) * ANB_ROWS_PER_WAVE;
+    for (int i = 0; i < ANB_ROWS_PER_WAVE; ++i) {
+        const int64_t row = row0 + i;
+        if (row >= nrows) break;
+        const int s = (int)(row / R);
+        const int64_t r = row - (int64_t)s * R;
+        const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
+        const float rstd = a.rstd[row];
+        const float mean = (a.is_rms || !a.mean) ? 0.f : a.mean[row];
+        float g[ANV_KMAX][4], xh[ANV_KMAX][4];  // output-channel order
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int k = 0; k < ANV_KMAX; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < D) {
+                const int oc = a.swap_flip ? (D - 4 - c) : c;
+                float dyv[4], sm[4], w[4];
+                ld4<TY>(dy + orow * D + oc, dyv);
+                ld4<float>(a.sum_saved + orow * D + oc, sm);
+                ld4<float>(a.weight + oc, w);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xh[k][q] = (sm[q] - mean) * rstd;
+                    g[k][q] = dyv[q] * w[q];
+                    sg += g[k][q];
+                    sgx += g[k][q] * xh[k][q];
+                    dw[k][q] += dyv[q] * xh[k][q];
+                    db[k][q] += dyv[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[k][q] = xh[k][q] = 0.f;
+            }
+        }
+        sgx = wave_sum(sgx) * invD;
+        sg = a.is_rms ? 0.f : wave_sum(sg) * invD;
+#pragma unroll
+        for (int k = 0; k < ANV_KMAX; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < D) {
+                const int oc = a.swap_flip ? (D - 4 - c) : c;
+                float dro[4] = {0.f, 0.f, 0.f, 0.f}, d[4];
+                if (a.dres_out) ld4<float>(a.dres_out + orow * D + oc, dro);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int qo = a.swap_flip ? (3 - q) : q;  // output element that input element q produced
+                    d[q] = rstd * (g[k][qo] - sg - xh[k][qo] * sgx) + dro[qo];
+                }
+                cad_cvt_store<TX, 4>(dx + row * D + c, d);
+                if (a.dres_in) cad_cvt_store<float, 4>(a.dres_in + row * D + c, d);
+            }
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !a.dbias) break;
+#pragma unroll
+        for (int k = 0; k < ANV_KMAX; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            const int oc = a.swap_flip ? (D - 4 - c) : c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c < D) red[wave][oc + q] = pass == 0 ? dw[k][q] : db[k][q];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += blockDim.x) {
+            float t = 0.f;
+            for (int w = 0; w < AN_WAVES; ++w) t += red[w][c];
+            if (t != 0.f) atomicAdd(pass == 0 ? &a.dweight[c] : &a.dbias[c], t);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream) {
@@ -167,12 +363,21 @@ extern "C" int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream) {
     int64_t nb = (nrows + AN_WAVES - 1) / AN_WAVES;
     if (nb > 8192) nb = 8192;
     dim3 grid((unsigned)nb), block(64 * AN_WAVES);
+    const bool vec = (a->D % 4) == 0 && (((uintptr_t)a->x | (uintptr_t)a->residual_in | (uintptr_t)a->weight |
+                                          (uintptr_t)a->bias | (uintptr_t)a->y | (uintptr_t)a->residual_out) % 16) == 0;
+#define AN_FWD(TX, TY)                                                                  \
+    do {                                                                                \
+        if (vec)                                                                        \
+            CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY>), grid, block, 0, stream, *a);  \
+        else                                                                            \
+            CAD_LAUNCH((add_norm_fwd_kernel<TX, TY>), grid, block, 0, stream, *a);      \
+    } while (0)
     if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_F32)
-        CAD_LAUNCH((add_norm_fwd_kernel<float, float>), grid, block, 0, stream, *a);
+        AN_FWD(float, float);
     else if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_BF16)
-        CAD_LAUNCH((add_norm_fwd_kernel<float, bf16_t>), grid, block, 0, stream, *a);
+        AN_FWD(float, bf16_t);
     else if (a->x_dtype == CAD_BF16 && a->y_dtype == CAD_BF16)
-        CAD_LAUNCH((add_norm_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, stream, *a);
+        AN_FWD(bf16_t, bf16_t);
     else
         return CAD_ERR_UNSUPPORTED;
     return cad_after_launch();
@@ -186,12 +391,21 @@ extern "C" int cad_add_norm_bwd(const cad_add_norm_bwd_args* a, void* stream) {
     const int64_t nrows = a->rows_per_strand * a->n_strands;
     const int64_t per_block = (int64_t)AN_WAVES * ANB_ROWS_PER_WAVE;
     dim3 grid((unsigned)((nrows + per_block - 1) / per_block)), block(64 * AN_WAVES);
+    const bool vec = (a->D % 4) == 0 && (((uintptr_t)a->dy | (uintptr_t)a->dres_out | (uintptr_t)a->sum_saved |
+                                          (uintptr_t)a->weight | (uintptr_t)a->dx | (uintptr_t)a->dres_in) % 16) == 0;
+#define AN_BWD(TX, TY)                                                                  \
+    do {                                                                                \
+        if (vec)                                                                        \
+            CAD_LAUNCH((add_norm_bwd_vec_kernel<TX, TY>), grid, block, 0, stream, *a);  \
+        else                                                                            \
+            CAD_LAUNCH((add_norm_bwd_kernel<TX, TY>), grid, block, 0, stream, *a);      \
+    } while (0)
     if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_F32)
-        CAD_LAUNCH((add_norm_bwd_kernel<float, float>), grid, block, 0, stream, *a);
+        AN_BWD(float, float);
     else if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_BF16)
-        CAD_LAUNCH((add_norm_bwd_kernel<float, bf16_t>), grid, block, 0, stream, *a);
+        AN_BWD(float, bf16_t);
     else if (a->x_dtype == CAD_BF16 && a->y_dtype == CAD_BF16)
-        CAD_LAUNCH((add_norm_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, stream, *a);
+        AN_BWD(bf16_t, bf16_t);
     else
         return CAD_ERR_UNSUPPORTED;
     return cad_after_launch();

@@ -75,6 +75,30 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {  // round-to-neare
     return r;
 }
 
+// two fp32 -> packed bf16x2 (lo in bits [15:0]); v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even)
+__device__ __forceinline__ uint32_t cad_pack_bf16x2(float lo, float hi) {
+#ifdef CAD_EMU
+    return (uint32_t)from_f32<bf16_t>(lo).v | ((uint32_t)from_f32<bf16_t>(hi).v << 16);
+#else
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#endif
+}
+// N fp32 values -> N contiguous elements of T at dst (N even, dst suitably aligned by the caller's vector type)
+template <typename T, int N>
+__device__ __forceinline__ void cad_cvt_store(T* dst, const float* v);
+template <>
+__device__ __forceinline__ void cad_cvt_store<float, 4>(float* dst, const float* v) {
+    struct __attribute__((aligned(16))) V { float f[4]; } t = {{v[0], v[1], v[2], v[3]}};
+    *(V*)dst = t;
+}
+template <>
+__device__ __forceinline__ void cad_cvt_store<bf16_t, 4>(bf16_t* dst, const float* v) {
+    struct __attribute__((aligned(8))) V { uint32_t w[2]; } t = {{cad_pack_bf16x2(v[0], v[1]), cad_pack_bf16x2(v[2], v[3])}};
+    *(V*)dst = t;
+}
+
 #define CAD_LOG2E 1.4426950408889634f
 
 __device__ __forceinline__ float cad_exp2(float x) {
@@ -108,12 +132,14 @@ __device__ __forceinline__ float cad_rsqrt(float x) {
 }
 // softplus with the upstream threshold (x > 20 -> x); log1p(e) evaluated as log(w) * e / (w - 1), w = 1 + e,
 // which is accurate to ~1 ulp also for tiny e (plain log(1+e) loses all digits there).
+// Branch-free (selects only): every lane evaluates both sides; NaN/inf of the unselected side is discarded.
 __device__ __forceinline__ float cad_softplus(float x) {
-    if (x > 20.0f) return x;
-    float e = cad_exp(x);
-    float w = 1.0f + e;
-    float d = w - 1.0f;
-    return (d == 0.0f) ? e : cad_log(w) * (e * cad_rcp(d));
+    const float e = cad_exp(x);
+    const float w = 1.0f + e;
+    const float d = w - 1.0f;
+    const float lp = cad_log(w) * (e * cad_rcp(d));
+    const float sp = (d == 0.0f) ? e : lp;
+    return (x > 20.0f) ? x : sp;
 }
 __device__ __forceinline__ float cad_sigmoid(float x) { return cad_rcp(1.0f + cad_exp(-x)); }
 

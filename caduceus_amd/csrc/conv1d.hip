@@ -135,6 +135,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(cad_conv1d_bwd_a
                 if (k < K) part[k] += dpre[j] * xs[CV_VEC + j - (K - 1) + k];
             part[CV_KMAX] += dpre[j];
         }
+        if (a.accumulate) {
+            float prev[CV_VEC];
+            load8(dx, p0, L, rev, vec_ok, prev);
+#pragma unroll
+            for (int j = 0; j < CV_VEC; ++j) o[j] += prev[j];
+        }
         store8(dx, p0, L, rev, vec_ok, o);
     }
     // block reduction of dw / dbias partials

@@ -177,10 +177,11 @@ __device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev,
     if constexpr (VEC) {
         if (p0 < L) {
             const int64_t l0 = rev ? (L - p0 - S) : p0;
-            ScVec<T, S> tmp;
+            float m[S];  // memory order
 #pragma unroll
-            for (int j = 0; j < S; ++j) tmp.v[rev ? (S - 1 - j) : j] = from_f32<T>(v[j]);
-            *(ScVec<T, S>*)(row + l0) = tmp;
+            for (int k = 0; k < S; ++k) m[k] = v[rev ? (S - 1 - k) : k];
+#pragma unroll
+            for (int k = 0; k < S; k += 4) cad_cvt_store<T, 4>(row + l0 + k, m + k);
         }
     } else {
 #pragma unroll

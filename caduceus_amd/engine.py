@@ -20,7 +20,7 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import mixer, ops
 
 
 def _w(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -67,6 +67,8 @@ def bimamba_tframe(hn: torch.Tensor, mamba_fwd, mamba_rev, strategy: Optional[st
     act = hn.dtype
     x2d = hn.reshape(T, D)
     split = B if (S == 2 and strand_swap) else SB
+    if mixer.can_use(mamba_fwd, mamba_rev, strategy):  # released-model configuration: hand-scheduled fwd/bwd
+        return mixer.bimamba_mixer(hn, mamba_fwd, mamba_rev, split)
     xz_f = _in_proj(mamba_fwd, x2d, SB, L, act)
     E = xz_f.shape[0] // 2
     set_f = _scan_inputs(xz_f, mamba_fwd, split, 0, 1, act)

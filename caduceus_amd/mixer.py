@@ -1,0 +1,183 @@
+"""Hand-scheduled forward/backward of one weight-tied BiMamba mixer over both RCPS strands (the production path:
+`bidirectional=True, bidirectional_strategy="add", bidirectional_weight_tie=True, bias=False`).
+
+engine.py composes the same computation from per-op autograd Functions (kept for every other configuration and as the
+readable specification).  Scheduling the backward by hand removes what generic autograd cannot know
+(profiles/r01_step_and_scan_v3_summary.txt: ~40 ms of copies / adds / duplicate GEMMs per 382 ms step):
+  * with a tied out_proj, d(y_f) == d(y_r): ONE GEMM, written channel-major directly (no transposing copies);
+  * the scan backward writes dz of parameter set f straight into the dxz buffer; set r's dz enters the in_proj backward
+    as a second, accumulating GEMM instead of an elementwise add pass;
+  * conv backward of set r accumulates onto set f's dx in-kernel; dB/dC partial sums are reduced straight into the rows of
+    the x_proj gradient operand; du is folded into the x_proj backward GEMM (addmm).
+All kernels are the C-ABI entry points of include/caduceus_hip.h; GEMMs are hipBLASLt through torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _conv_fwd(x, wf, bf, split, rl, rh):
+    E, SB, Lq = x.shape
+    out = torch.empty_like(x)
+    stream = L.stream_and_check(x, wf, bf, out)
+    a = L.Conv1dArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(out), SB, Lq, split, E, wf.shape[1], rl, rh,
+                     L.dtype_code(x.dtype))
+    L.check(L.get_lib().cad_conv1d_fwd(C.byref(a), stream), "cad_conv1d_fwd")
+    return out
+
+
+def _conv_bwd(x, wf, bf, dout, dx, split, rl, rh, accumulate):
+    E, SB, Lq = x.shape
+    dw = torch.zeros_like(wf)
+    db = None if bf is None else torch.zeros_like(bf)
+    stream = L.stream_and_check(x, wf, bf, dout, dx, dw, db)
+    a = L.Conv1dBwdArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(dout), L.ptr(dx), L.ptr(dw), L.ptr(db), SB, Lq, split, E,
+                        wf.shape[1], rl, rh, L.dtype_code(x.dtype), int(accumulate))
+    L.check(L.get_lib().cad_conv1d_bwd(C.byref(a), stream), "cad_conv1d_bwd")
+    return dw, db
+
+
+class BiMambaMixerFn(torch.autograd.Function):
+    """out (T, D) = out_proj(scan_f + scan_r) for normed input x2d (T, D), T = S*B*L rows in t-frame order.
+
+    Tensor arguments: x2d, W_in (2E, D), W_out (D, E), then per parameter set (f, r):
+    conv_w (E,1,K), conv_b (E), W_x (R+2N, E), W_dt (E, R), dt_bias (E), A_log (E, N), D (E)."""
+
+    @staticmethod
+    def forward(ctx, x2d, SB, Lq, split, W_in, W_out, *ps):
+        lib = L.get_lib()
+        act = x2d.dtype
+        T, Dm = x2d.shape
+        E = W_in.shape[0] // 2
+        w_in = W_in.to(act)
+        w_out = W_out.to(act)
+        xz = torch.mm(w_in, x2d.t()).view(2 * E, SB, Lq)
+        x, z = xz[:E], xz[E:]
+        sets, saved = [], []
+        dirs = ((0, 1), (1, 0))
+        for i in range(2):
+            conv_w, conv_b, W_x, W_dt, dt_bias, A_log, Dp = ps[7 * i:7 * i + 7]
+            N, R = A_log.shape[1], W_dt.shape[1]
+            wf = conv_w.float().reshape(E, -1).contiguous()
+            bf = None if conv_b is None else conv_b.float().contiguous()
+            xc = _conv_fwd(x, wf, bf, split, *dirs[i])
+            w_x, w_dt = W_x.to(act), W_dt.to(act)
+            dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
+            delta = torch.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
+            A = -torch.exp(A_log.float())
+            sets.append((xc, delta, A, dbc, Dp.float().contiguous(), dt_bias.float().contiguous(), wf, bf, w_x, w_dt))
+        # both parameter sets in one scan launch
+        args = (L.ScanArgs * 2)()
+        outs, states = [], []
+        for i, (xc, delta, A, dbc, Df, bfz, *_rest) in enumerate(sets):
+            N, R = A.shape[1], dbc.shape[0] - 2 * A.shape[1]
+            out = torch.empty_like(xc)
+            state = torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=xc.device)
+            Bm, Cm = dbc[R:R + N], dbc[R + N:]
+            stream = L.stream_and_check(xc, delta, A, Bm, Cm, Df, z, bfz, out, state)
+            args[i] = L.ScanArgs(L.ptr(xc), L.ptr(delta), L.ptr(A), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bfz),
+                                 L.ptr(out), L.ptr(state), SB, Lq, split, E, N, dirs[i][0], dirs[i][1],
+                                 L.dtype_code(act))
+            outs.append(out)
+            states.append(state)
+        L.check(lib.cad_scan_fwd_multi(args, 2, stream), "cad_scan_fwd_multi")
+        y_f, y_r = outs
+        out2d = torch.mm(y_f.view(E, T).t(), w_out.t())
+        out2d = torch.addmm(out2d, y_r.view(E, T).t(), w_out.t())
+        keep = [x2d, xz, w_in, w_out, y_f, y_r]
+        for i in range(2):
+            xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt = sets[i]
+            keep += [xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, states[i], ps[7 * i + 5]]
+        ctx.save_for_backward(*keep)
+        ctx.meta = (SB, Lq, split, [tuple(None if p is None else (p.dtype, p.shape) for p in ps[7 * i:7 * i + 7])
+                                    for i in range(2)], W_in.dtype, W_out.dtype)
+        return out2d
+
+    @staticmethod
+    def backward(ctx, dout2d):
+        lib = L.get_lib()
+        x2d, xz, w_in, w_out, y_f, y_r, *rest = ctx.saved_tensors
+        SB, Lq, split, pmeta, win_dt, wout_dt = ctx.meta
+        act = x2d.dtype
+        T, Dm = x2d.shape
+        E = xz.shape[0] // 2
+        x, z = xz[:E], xz[E:]
+        dirs = ((0, 1), (1, 0))
+        dout2d = dout2d.contiguous()
+        # tied out_proj: the gradient w.r.t. y_f and y_r is the same tensor, produced channel-major
+        dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)
+        dW_out = torch.mm(dout2d.t(), y_f.view(E, T).t())
+        dW_out = torch.addmm(dW_out, dout2d.t(), y_r.view(E, T).t())
+        dxz = torch.empty_like(xz)       # [dx ; dz_f]
+        dz_r = torch.empty_like(z)
+        sets = [rest[12 * i:12 * i + 12] for i in range(2)]
+        args = (L.ScanBwdArgs * 2)()
+        work = []
+        for i in range(2):
+            xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
+            N = A.shape[1]
+            R = dbc.shape[0] - 2 * N
+            du, ddelta = torch.empty_like(xc), torch.empty_like(xc)
+            dz = dxz[E:] if i == 0 else dz_r
+            dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Df), torch.zeros_like(bfz)
+            npart = lib.cad_scan_bwd_partials(E)
+            dBC = torch.empty((2, npart, N, SB, Lq), dtype=torch.float32, device=xc.device)
+            Bm, Cm = dbc[R:R + N], dbc[R + N:]
+            stream = L.stream_and_check(xc, delta, A, Bm, Cm, Df, z, bfz, dy, state, du, ddelta, dz, dA, dBC, dD, dbias)
+            args[i] = L.ScanBwdArgs(L.ptr(xc), L.ptr(delta), L.ptr(A), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
+                                    L.ptr(bfz), L.ptr(dy), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
+                                    L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
+                                    dirs[i][0], dirs[i][1], L.dtype_code(act), npart)
+            work.append((du, ddelta, dA, dD, dbias, dBC, npart))
+        L.check(lib.cad_scan_bwd_multi(args, 2, stream), "cad_scan_bwd_multi")
+        grads = []
+        for i in range(2):
+            xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
+            du, ddelta, dA, dD, dbias, dBC, npart = work[i]
+            N = A.shape[1]
+            R = dbc.shape[0] - 2 * N
+            # gradient of [dt_lr ; B ; C] assembled in place: rows [R:] by the partial-slot reduction, rows [:R] by a GEMM
+            ddbc = torch.empty_like(dbc)
+            n = N * SB * Lq
+            L.check(lib.cad_reduce_partials(L.ptr(dBC[0]), npart, n, L.ptr(ddbc[R:R + N]), L.dtype_code(act), stream),
+                    "cad_reduce_partials")
+            L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
+                    "cad_reduce_partials")
+            torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+            dW_dt = torch.mm(ddelta.view(E, T), dbc[:R].view(R, T).t())
+            dW_x = torch.mm(ddbc.view(R + 2 * N, T), xc.view(E, T).t())
+            dxc = torch.addmm(du.view(E, T), w_x.t(), ddbc.view(R + 2 * N, T)).view(E, SB, Lq)
+            dwc, dbc_conv = _conv_bwd(x, wf, bf, dxc, dxz[:E], split, dirs[i][0], dirs[i][1], accumulate=(i == 1))
+            meta = pmeta[i]
+            dA_log = (dA * A).to(meta[5][0])  # A = -exp(A_log)  =>  dA/dA_log = A
+            grads += [dwc.reshape(meta[0][1]).to(meta[0][0]), None if dbc_conv is None else dbc_conv.to(meta[1][0]),
+                      dW_x.to(meta[2][0]), dW_dt.to(meta[3][0]), dbias.to(meta[4][0]), dA_log, dD.to(meta[6][0])]
+        dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
+        dx2d = torch.addmm(dx2d, dz_r.view(E, T).t(), w_in[E:])
+        dW_in = torch.mm(dxz.view(2 * E, T), x2d)
+        dW_in[E:] += torch.mm(dz_r.view(E, T), x2d)
+        return (dx2d, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
+
+
+def can_use(mamba_fwd, mamba_rev, strategy) -> bool:
+    """The hand-scheduled path covers the released-model configuration; everything else goes through engine.py."""
+    if mamba_rev is None or (strategy or "add") != "add":
+        return False
+    tied = (mamba_rev.in_proj.weight is mamba_fwd.in_proj.weight and mamba_rev.out_proj.weight is mamba_fwd.out_proj.weight)
+    no_bias = mamba_fwd.in_proj.bias is None and mamba_fwd.out_proj.bias is None
+    same = mamba_fwd.d_state == mamba_rev.d_state and mamba_fwd.dt_rank == mamba_rev.dt_rank
+    return bool(tied and no_bias and same)
+
+
+def bimamba_mixer(hn: torch.Tensor, mamba_fwd, mamba_rev, split: int) -> torch.Tensor:
+    S, B, Lq, Dm = hn.shape
+    ps = []
+    for m in (mamba_fwd, mamba_rev):
+        ps += [m.conv1d.weight, m.conv1d.bias, m.x_proj.weight, m.dt_proj.weight, m.dt_proj.bias, m.A_log, m.D]
+    out = BiMambaMixerFn.apply(hn.reshape(S * B * Lq, Dm), S * B, Lq, split, mamba_fwd.in_proj.weight,
+                               mamba_fwd.out_proj.weight, *ps)
+    return out.view(S, B, Lq, Dm)

@@ -147,7 +147,7 @@ class _Conv1d(torch.autograd.Function):
         db = torch.zeros((E,), dtype=torch.float32, device=x.device) if has_bias else None
         stream = L.stream_and_check(x, wf, bf, dout, dx, dw, db)
         a = L.Conv1dBwdArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(dout), L.ptr(dx), L.ptr(dw), L.ptr(db), SB, Lq, split,
-                            E, wf.shape[1], rev_lo, rev_hi, L.dtype_code(x.dtype))
+                            E, wf.shape[1], rev_lo, rev_hi, L.dtype_code(x.dtype), 0)
         L.check(L.get_lib().cad_conv1d_bwd(C.byref(a), stream), "cad_conv1d_bwd")
         return dx, dw.reshape(wshape).to(wdt), (None if db is None else db.to(wdt)), None, None, None
 

@@ -141,7 +141,8 @@ typedef struct {
     int dtype;
 } cad_conv1d_args;
 int cad_conv1d_fwd(const cad_conv1d_args* a, void* stream);
-/* dx is WRITTEN (dtype); dw (E,K) and dbias (E) fp32 are ACCUMULATED (caller zeroes). */
+/* dx is WRITTEN (dtype), or ADDED to when accumulate != 0 (the second parameter set of a BiMamba layer adds its input
+ * gradient onto the first one's); dw (E,K) and dbias (E) fp32 are ACCUMULATED (caller zeroes). */
 typedef struct {
     const void* x;
     const float* w;
@@ -154,6 +155,7 @@ typedef struct {
     int E, K;
     int rev_lo, rev_hi;
     int dtype;
+    int accumulate;
 } cad_conv1d_bwd_args;
 int cad_conv1d_bwd(const cad_conv1d_bwd_args* a, void* stream);
 
