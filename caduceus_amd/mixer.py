@@ -5,8 +5,9 @@ engine.py composes the same computation from per-op autograd Functions (kept for
 readable specification).  Scheduling the backward by hand removes what generic autograd cannot know
 (profiles/r01_step_and_scan_v3_summary.txt: ~40 ms of copies / adds / duplicate GEMMs per 382 ms step):
   * with a tied out_proj, d(y_f) == d(y_r): ONE GEMM, written channel-major directly (no transposing copies);
-  * the scan backward writes dz of parameter set f straight into the dxz buffer; set r's dz enters the in_proj backward
-    as a second, accumulating GEMM instead of an elementwise add pass;
+  * the scan backward writes dz of parameter set f straight into the dxz buffer and set r's dz is added in place;
+  * weight gradients (reductions over all T tokens with tiny outputs) run as strided-batch GEMMs over 64 K-chunks plus an
+    fp32 sum, 3-5x faster than the un-split library GEMM;
   * conv backward of set r accumulates onto set f's dx in-kernel; dB/dC partial sums are reduced straight into the rows of
     the x_proj gradient operand; du is folded into the x_proj backward GEMM (addmm).
 All kernels are the C-ABI entry points of include/caduceus_hip.h; GEMMs are hipBLASLt through torch.
@@ -39,6 +40,36 @@ def _conv_bwd(x, wf, bf, dout, dx, split, rl, rh, accumulate):
                         wf.shape[1], rl, rh, L.dtype_code(x.dtype), int(accumulate))
     L.check(L.get_lib().cad_conv1d_bwd(C.byref(a), stream), "cad_conv1d_bwd")
     return dw, db
+
+
+def _kchunks(T: int) -> int:
+    """Number of K-chunks for the weight-gradient GEMMs (reduction over all T tokens, tiny outputs).  hipBLASLt does not
+    split K by itself for these shapes (0.6 ms at 0.65 TB/s); as a strided-batch GEMM over 64 chunks plus an fp32 sum of
+    the partial products the same gradient takes 0.1-0.2 ms (tools/gemm_bench.py), with the same rounding error."""
+    n = 64
+    while n > 1 and (T % n != 0 or T // n < 1024):
+        n //= 2
+    return n
+
+
+def _wgrad_cm_cm(a_cm: torch.Tensor, b_cm: torch.Tensor) -> torch.Tensor:
+    """a (M, T) @ b (N, T)^T with both operands channel-major (T contiguous) -> (M, N) fp32."""
+    M, T = a_cm.shape
+    n = _kchunks(T)
+    if n == 1:
+        return torch.mm(a_cm, b_cm.t()).float()
+    Kc = T // n
+    return torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_cm.view(-1, n, Kc).permute(1, 2, 0)).float().sum(0)
+
+
+def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
+    """a (M, T) channel-major @ b (T, N) token-major -> (M, N) fp32."""
+    M, T = a_cm.shape
+    n = _kchunks(T)
+    if n == 1:
+        return torch.mm(a_cm, b_tm).float()
+    Kc = T // n
+    return torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_tm.view(n, Kc, -1)).float().sum(0)
 
 
 class BiMambaMixerFn(torch.autograd.Function):
@@ -110,9 +141,8 @@ class BiMambaMixerFn(torch.autograd.Function):
         dout2d = dout2d.contiguous()
         # tied out_proj: the gradient w.r.t. y_f and y_r is the same tensor, produced channel-major
         dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)
-        dW_out = torch.mm(dout2d.t(), y_f.view(E, T).t())
-        dW_out = torch.addmm(dW_out, dout2d.t(), y_r.view(E, T).t())
-        dxz = torch.empty_like(xz)       # [dx ; dz_f]
+        dW_out = (_wgrad_cm_tm(y_f.view(E, T), dout2d) + _wgrad_cm_tm(y_r.view(E, T), dout2d)).t()
+        dxz = torch.empty_like(xz)       # [dx ; dz_f + dz_r]
         dz_r = torch.empty_like(z)
         sets = [rest[12 * i:12 * i + 12] for i in range(2)]
         args = (L.ScanBwdArgs * 2)()
@@ -148,18 +178,17 @@ class BiMambaMixerFn(torch.autograd.Function):
             L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
                     "cad_reduce_partials")
             torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
-            dW_dt = torch.mm(ddelta.view(E, T), dbc[:R].view(R, T).t())
-            dW_x = torch.mm(ddbc.view(R + 2 * N, T), xc.view(E, T).t())
+            dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
+            dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
             dxc = torch.addmm(du.view(E, T), w_x.t(), ddbc.view(R + 2 * N, T)).view(E, SB, Lq)
             dwc, dbc_conv = _conv_bwd(x, wf, bf, dxc, dxz[:E], split, dirs[i][0], dirs[i][1], accumulate=(i == 1))
             meta = pmeta[i]
             dA_log = (dA * A).to(meta[5][0])  # A = -exp(A_log)  =>  dA/dA_log = A
             grads += [dwc.reshape(meta[0][1]).to(meta[0][0]), None if dbc_conv is None else dbc_conv.to(meta[1][0]),
                       dW_x.to(meta[2][0]), dW_dt.to(meta[3][0]), dbias.to(meta[4][0]), dA_log, dD.to(meta[6][0])]
+        dxz[E:].add_(dz_r)  # the two parameter sets share the gate z
         dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
-        dx2d = torch.addmm(dx2d, dz_r.view(E, T).t(), w_in[E:])
-        dW_in = torch.mm(dxz.view(2 * E, T), x2d)
-        dW_in[E:] += torch.mm(dz_r.view(E, T), x2d)
+        dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
         return (dx2d, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
 
 

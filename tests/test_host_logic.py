@@ -132,3 +132,14 @@ def test_tokenizer_ids_and_complement_map():
     assert tok.padding_side == "left" and tok.pad_token_id == 4 and tok.mask_token_id == 3
     assert tok.build_inputs_with_special_tokens([7, 8]) == [7, 8, 1]
     CaduceusTokenizer(model_max_length=16, add_special_tokens=False)  # the reference's constructor call (genomics.py:108-111)
+
+
+def test_chunked_weight_gradient_gemms_match_plain_mm():
+    """caduceus_amd/mixer.py: the K-chunked strided-batch formulation of the weight gradients is the same product."""
+    from caduceus_amd import mixer
+    g = torch.Generator().manual_seed(0)
+    T = 8192
+    assert mixer._kchunks(T) == 8 and mixer._kchunks(262144) == 64 and mixer._kchunks(100) == 1
+    a, b_cm, b_tm = torch.randn(24, T, generator=g), torch.randn(10, T, generator=g), torch.randn(T, 12, generator=g)
+    torch.testing.assert_close(mixer._wgrad_cm_cm(a, b_cm), a @ b_cm.t(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(mixer._wgrad_cm_tm(a, b_tm), a @ b_tm, rtol=1e-4, atol=1e-3)
