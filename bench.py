@@ -103,7 +103,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CADUCEUS_DP_FORCE_COLLECTIVE") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
 
     torch.manual_seed(2222)  # configs/experiment/hg38/hg38.yaml:54; identical initial weights on every rank
@@ -132,7 +133,7 @@ def main():
         return out.loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,7 +151,7 @@ def main():
     prof = _lib.prof_read()
     _lib.prof_reset()
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -197,7 +198,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -97,6 +97,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float ddt[SC_S], ddu[SC_S], y[SC_S];
         f32x2 dd[SC_S], ee[SC_S];  // (dt, dt * u) and (dy, u)
+#ifndef SC_BWD_PREFETCH
+        if (c != nchunks - 1) {
+            sc_load_raw<T, SC_S, VEC>(u_row, p0, L, rev, u_raw);
+            sc_load_raw<T, SC_S, VEC>(d_row, p0, L, rev, d_raw);
+            sc_load_raw<T, SC_S, VEC>(g_row, p0, L, rev, g_raw);
+            if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
+        }
+#endif
         {
             float uu[SC_S], dt[SC_S], dy[SC_S];
             sc_unpack<T, SC_S>(u_raw, rev, uu);
@@ -127,12 +135,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
             hin_reg = f2(stp[0], stp[1]);
         }
+#ifdef SC_BWD_PREFETCH
         if (c > 0) {  // prefetch the item vectors of the next (earlier) chunk
             sc_load_raw<T, SC_S, VEC>(u_row, p0 - SC_CHUNK, L, rev, u_raw);
             sc_load_raw<T, SC_S, VEC>(d_row, p0 - SC_CHUNK, L, rev, d_raw);
             sc_load_raw<T, SC_S, VEC>(g_row, p0 - SC_CHUNK, L, rev, g_raw);
             if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0 - SC_CHUNK, L, rev, z_raw);
         }
+#endif
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);

@@ -26,7 +26,7 @@
 #define SC_S_BWD 8
 #endif
 #ifndef SC_W_FWD
-#define SC_W_FWD 4              // waves (= channels) per forward workgroup
+#define SC_W_FWD 8              // waves (= channels) per forward workgroup (measured: 8 beats 4 by 13 %)
 #endif
 #ifndef SC_W_BWD
 #define SC_W_BWD 8              // waves (= channels) per backward workgroup: dB/dC are summed over them in LDS

@@ -16,6 +16,7 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE]
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
+    constexpr int SLOTS = SC_CHUNK / SC_STATE_STEP;  // saved-state slots per forward chunk (1 or 2)
     const cad_scan_args& a = sets.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             y[i] = Dv * du[i];
             dd[i] = f2(dti, dti * du[i]);
         }
-        // running state at this chunk's start (state slot 2c); the mid-chunk state (slot 2c+1) is written per pair
-        float* st_base = a.chunk_state ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + 2 * c) * NP * 2 : nullptr;
+        // running state at this chunk's start (first slot of the chunk); a mid-chunk state (second slot) is written per pair
+        float* st_base = a.chunk_state ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + SLOTS * c) * NP * 2 : nullptr;
         if (st_base && act && lane < NP) {
             st_base[lane * 2] = carry[0];
             st_base[lane * 2 + 1] = carry[1];
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             const f32x2 hin = readlane2(carry, np);
             const f32x2 h0 = ea * hin + eh;
             // state entering lane 32 = state at logical position base + 512: the backward's half-chunk start
-            if (st_base && act && base + SC_STATE_STEP < L) {
+            if (SLOTS == 2 && st_base && act && base + SC_STATE_STEP < L) {
                 const f32x2 mid = readlane2(h0, SC_STATE_STEP / SC_S);
                 if (lane == 0) {
                     st_base[(NP + np) * 2] = mid[0];
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
 
 }  // namespace
 
-static_assert(SC_CHUNK == 2 * SC_STATE_STEP, "forward chunk = two state slots");
+static_assert(SC_CHUNK == SC_STATE_STEP || SC_CHUNK == 2 * SC_STATE_STEP, "forward chunk = one or two state slots");
 
 extern "C" int64_t cad_scan_chunk_len(void) { return SC_CHUNK; }
 

@@ -10,6 +10,7 @@ Sequences are independent, so there is no other collective on the data path (SUR
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -22,6 +23,8 @@ class BucketedGradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.average = average
+        # testing aid: run the collectives even in a 1-rank group (exercises the RCCL path on a single GPU)
+        self._force = os.environ.get("CADUCEUS_DP_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
         seen, plist = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:  # tied parameters appear once
@@ -74,14 +77,14 @@ class BucketedGradReducer:
             view.copy_(p.grad)
             p.grad = view
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.sync_enabled and self.world > 1:
+        if self._pending[bi] == 0 and self.sync_enabled and (self.world > 1 or self._force):
             if self.average:
                 flat.div_(self.world)
             self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Call after backward: waits for the outstanding all-reduces (and launches any that never triggered)."""
-        if self.sync_enabled and self.world > 1:
+        if self.sync_enabled and (self.world > 1 or self._force):
             for bi, flat in enumerate(self.buckets):
                 if self._handles[bi] is None:
                     if self.average:
