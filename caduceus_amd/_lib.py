@@ -66,7 +66,7 @@ class ScanArgs(C.Structure):
 
 class ScanBwdArgs(C.Structure):
     _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
-                ("delta_bias", _p), ("dout", _p), ("chunk_state", _p), ("du", _p), ("ddelta", _p), ("dz", _p),
+                ("delta_bias", _p), ("dout", _p), ("out", _p), ("chunk_state", _p), ("du", _p), ("ddelta", _p), ("dz", _p),
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
                 ("n_partials", _i)]

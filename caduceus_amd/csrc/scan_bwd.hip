@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const T* d_row = (const T*)a.delta + row_off;
     const T* z_row = a.z ? (const T*)a.z + row_off : nullptr;
     const T* g_row = (const T*)a.dout + row_off;
+    const T* o_row = a.out ? (const T*)a.out + row_off : nullptr;
     T* du_row = (T*)a.du + row_off;
     T* dd_row = (T*)a.ddelta + row_off;
     T* dz_row = a.dz ? (T*)a.dz + row_off : nullptr;
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const float keep = act ? 1.f : 0.f;  // padding waves (E % SC_W != 0) contribute nothing
     const int64_t part_stride = (int64_t)N * SB * L;
-    float* dBg = a.dB + (int64_t)blockIdx.x * part_stride;  // this workgroup's partial-sum slot
-    float* dCg = a.dC + (int64_t)blockIdx.x * part_stride;
+    T* dBg = (T*)a.dB + (int64_t)blockIdx.x * part_stride;  // this workgroup's partial-sum slot
+    T* dCg = (T*)a.dC + (int64_t)blockIdx.x * part_stride;
 
     StageRegs<T, SC_SV(SC_S)> st;
     ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw;
@@ -95,8 +96,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     for (int64_t c = nchunks - 1; c >= 0; --c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
-        float ddt[SC_S], ddu[SC_S], y[SC_S];
+        float ddt[SC_S], ddu[SC_S];
         f32x2 dd[SC_S], ee[SC_S];  // (dt, dt * u) and (dy, u)
+        float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
 #ifndef SC_BWD_PREFETCH
         if (c != nchunks - 1) {
             sc_load_raw<T, SC_S, VEC>(u_row, p0, L, rev, u_raw);
@@ -121,11 +123,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const bool ok = p0 + i < L;
                 const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
-                y[i] = Dv * uu[i];
                 ddt[i] = 0.f;
                 ddu[i] = dyi * Dv;
                 dDacc += dyi * uu[i];
                 dd[i] = f2(dti, dti * uu[i]);
+                sum_dt += dti;
                 ee[i] = f2(dyi, uu[i]);
             }
         }
@@ -161,13 +163,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const f32x2 hin = readlane2(hin_reg, np);
             // 1. forward recompute: serial totals, wave scan, then the true h_i
             f32x2 av[SC_S], hs[SC_S];
-            f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
+            f32x2 acc_h = f2(0.f);
+            const f32x2 acc_a = exp2_2(f2(sum_dt) * A2);  // product of the lane's a_i
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 av[i] = exp2_2(splat_lo(dd[i]) * A2);
                 hs[i] = splat_hi(dd[i]) * ld2(tB + 2 * i);  // b_i
                 acc_h = av[i] * acc_h + hs[i];
-                acc_a = acc_a * av[i];
             }
             f32x2 PA = acc_a, PH = acc_h;
             wave_scan_fwd(PA, PH);
@@ -180,7 +182,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 for (int i = 0; i < SC_S; ++i) {
                     h = av[i] * h + hs[i];
                     hs[i] = h;  // h_i
-                    y[i] += dot2(ld2(tC + 2 * i), h);
                 }
             }
             // 2. reverse scan of G
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const f32x2 g = ld2(tC + 2 * i) * splat_lo(ee[i]) + G;
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
-                const f32x2 t = g * hprev * av[i];
+                const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
                 const float gB = dot2(g, Bv);
                 ddt[i] += dot2(t, Av) + ee[i][1] * gB;
                 ddu[i] += dd[i][0] * gB;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const int t = threadIdx.x;
                 const int s = (t >> 7) & 1;
                 const float* tile = acc + buf * ACC_BUF + (t >> 8) * ACC_TILE;
-                float* grow = ((t >> 8) ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
+                T* grow = ((t >> 8) ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
                 const int tok = (t & 127) * 4;
                 const int j = tok / SC_S, i0 = tok % SC_S;
                 float v[4];
@@ -239,22 +240,17 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     const int64_t p = base + tok;
                     if (VEC) {
                         if (p < L) {
-                            typedef struct __attribute__((aligned(16))) {
-                                float f[4];
-                            } v4;
-                            v4 o;
                             if (rev) {
-                                o.f[0] = v[3], o.f[1] = v[2], o.f[2] = v[1], o.f[3] = v[0];
-                                *(v4*)(grow + (L - p - 4)) = o;
+                                const float o[4] = {v[3], v[2], v[1], v[0]};
+                                cad_cvt_store<T, 4>(grow + (L - p - 4), o);
                             } else {
-                                o.f[0] = v[0], o.f[1] = v[1], o.f[2] = v[2], o.f[3] = v[3];
-                                *(v4*)(grow + p) = o;
+                                cad_cvt_store<T, 4>(grow + p, v);
                             }
                         }
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (p + q < L) grow[cad_phys(p + q, L, rev)] = v[q];
+                            if (p + q < L) grow[cad_phys(p + q, L, rev)] = from_f32<T>(v[q]);
                     }
                 }
             }
@@ -274,13 +270,16 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
         }
         if (dz_row) {
-            float zz[SC_S], go[SC_S];
+            // out = y * z * sigmoid(z)  =>  y * sigmoid(z) = out / z ;  dz = dout * y * sigmoid(z) * (1 + z (1 - sigmoid(z)))
+            float zz[SC_S], go[SC_S], oo[SC_S];
             sc_load<T, SC_S, VEC>(z_row, p0, L, rev, zz);
             sc_load<T, SC_S, VEC>(g_row, p0, L, rev, go);
+            sc_load<T, SC_S, VEC>(o_row, p0, L, rev, oo);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const float sg = cad_sigmoid(zz[i]);
-                go[i] = go[i] * y[i] * sg * (1.f + zz[i] * (1.f - sg));
+                const float ys = (zz[i] == 0.f) ? 0.f : oo[i] * cad_rcp(zz[i]);
+                go[i] = go[i] * ys * (1.f + zz[i] * (1.f - sg));
             }
             if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, go);
         }
@@ -299,26 +298,40 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     }
 }
 
-// dst[i] = sum_k src[k * n + i]  (fp32 partial slots -> dtype); 4 elements per thread, 16-byte accesses
+// dst[i] = sum_k src[k * n + i]  (partial slots in T, fp32 accumulation); 4 elements per thread
 template <typename T>
-__global__ void reduce_partials_kernel(const float* src, int nparts, int64_t n, T* dst) {
+__device__ __forceinline__ void ld4p(const T* p, float* o);
+template <>
+__device__ __forceinline__ void ld4p<float>(const float* p, float* o) {
+    struct __attribute__((aligned(16))) V { float f[4]; };
+    const V t = *(const V*)p;
+    o[0] = t.f[0], o[1] = t.f[1], o[2] = t.f[2], o[3] = t.f[3];
+}
+template <>
+__device__ __forceinline__ void ld4p<bf16_t>(const bf16_t* p, float* o) {
+    struct __attribute__((aligned(8))) V { uint32_t w[2]; };
+    const V t = *(const V*)p;
+    o[0] = cad_bits2f(t.w[0] << 16), o[1] = cad_bits2f(t.w[0] & 0xffff0000u);
+    o[2] = cad_bits2f(t.w[1] << 16), o[3] = cad_bits2f(t.w[1] & 0xffff0000u);
+}
+
+template <typename T>
+__global__ void reduce_partials_kernel(const T* src, int nparts, int64_t n, T* dst, int vec) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
-        if (i + 4 <= n && (n % 4) == 0) {
-            typedef struct __attribute__((aligned(16))) {
-                float f[4];
-            } v4;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (vec && i + 4 <= n) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < nparts; ++k) {
-                const v4 x = *(const v4*)(src + (int64_t)k * n + i);
-                s0 += x.f[0], s1 += x.f[1], s2 += x.f[2], s3 += x.f[3];
+                float x[4];
+                ld4p<T>(src + (int64_t)k * n + i, x);
+                s[0] += x[0], s[1] += x[1], s[2] += x[2], s[3] += x[3];
             }
-            dst[i] = from_f32<T>(s0), dst[i + 1] = from_f32<T>(s1), dst[i + 2] = from_f32<T>(s2), dst[i + 3] = from_f32<T>(s3);
+            cad_cvt_store<T, 4>(dst + i, s);
         } else {
             for (int64_t q = i; q < n && q < i + 4; ++q) {
-                float s = 0.f;
-                for (int k = 0; k < nparts; ++k) s += src[(int64_t)k * n + q];
-                dst[q] = from_f32<T>(s);
+                float acc = 0.f;
+                for (int k = 0; k < nparts; ++k) acc += to_f32(src[(int64_t)k * n + q]);
+                dst[q] = from_f32<T>(acc);
             }
         }
     }
@@ -336,6 +349,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
         CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && a->dout && a->chunk_state);
         CAD_CHECK_ARG(a->du && a->ddelta && a->dA && a->dB && a->dC);
         CAD_CHECK_ARG((a->z == nullptr) == (a->dz == nullptr));
+        CAD_CHECK_ARG(a->z == nullptr || a->out != nullptr);
         CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
         CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
         CAD_CHECK_ARG(a->n_partials == cad_scan_bwd_partials(a->E));
@@ -347,7 +361,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     const cad_scan_bwd_args* a = &sets[0];
     bool vec = (a->L % SC_S) == 0;
     for (int i = 0; i < nsets; ++i)
-        vec = vec && (((uintptr_t)sets[i].u | (uintptr_t)sets[i].delta | (uintptr_t)sets[i].z | (uintptr_t)sets[i].dout |
+        vec = vec && (((uintptr_t)sets[i].u | (uintptr_t)sets[i].delta | (uintptr_t)sets[i].z | (uintptr_t)sets[i].dout | (uintptr_t)sets[i].out |
                        (uintptr_t)sets[i].du | (uintptr_t)sets[i].ddelta | (uintptr_t)sets[i].dz |
                        (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm | (uintptr_t)sets[i].dB | (uintptr_t)sets[i].dC) %
                       16) == 0;
@@ -372,15 +386,16 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
 
 extern "C" int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream) { return cad_scan_bwd_multi(a, 1, stream); }
 
-extern "C" int cad_reduce_partials(const float* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream) {
+extern "C" int cad_reduce_partials(const void* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream) {
     CAD_CHECK_ARG(src && dst && n_partials >= 1 && n > 0);
+    const int vec = (n % 4) == 0 && (((uintptr_t)src | (uintptr_t)dst) % 16) == 0;
     int64_t nb = (n / 4 + 255) / 256 + 1;
     if (nb > 16384) nb = 16384;
     dim3 grid((unsigned)nb), block(256);
     if (dst_dtype == CAD_F32)
-        CAD_LAUNCH((reduce_partials_kernel<float>), grid, block, 0, stream, src, n_partials, n, (float*)dst);
+        CAD_LAUNCH((reduce_partials_kernel<float>), grid, block, 0, stream, (const float*)src, n_partials, n, (float*)dst, vec);
     else if (dst_dtype == CAD_BF16)
-        CAD_LAUNCH((reduce_partials_kernel<bf16_t>), grid, block, 0, stream, src, n_partials, n, (bf16_t*)dst);
+        CAD_LAUNCH((reduce_partials_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, n_partials, n, (bf16_t*)dst, vec);
     else
         return CAD_ERR_UNSUPPORTED;
     return cad_after_launch();

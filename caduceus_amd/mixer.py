@@ -155,11 +155,12 @@ class BiMambaMixerFn(torch.autograd.Function):
             dz = dxz[E:] if i == 0 else dz_r
             dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Df), torch.zeros_like(bfz)
             npart = lib.cad_scan_bwd_partials(E)
-            dBC = torch.empty((2, npart, N, SB, Lq), dtype=torch.float32, device=xc.device)
+            dBC = torch.empty((2, npart, N, SB, Lq), dtype=act, device=xc.device)
             Bm, Cm = dbc[R:R + N], dbc[R + N:]
             stream = L.stream_and_check(xc, delta, A, Bm, Cm, Df, z, bfz, dy, state, du, ddelta, dz, dA, dBC, dD, dbias)
             args[i] = L.ScanBwdArgs(L.ptr(xc), L.ptr(delta), L.ptr(A), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
-                                    L.ptr(bfz), L.ptr(dy), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
+                                    L.ptr(bfz), L.ptr(dy), L.ptr(y_f if i == 0 else y_r), L.ptr(state), L.ptr(du),
+                                    L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
                                     L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
                                     dirs[i][0], dirs[i][1], L.dtype_code(act), npart)
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))

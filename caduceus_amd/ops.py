@@ -189,7 +189,7 @@ class _ScanMulti(torch.autograd.Function):
             rl, rh = dirs[i]
             args[i] = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
                                  L.ptr(out), L.ptr(state), SB, Lq, split, E, N, rl, rh, L.dtype_code(u.dtype))
-            sets.append((u, delta, Af, Bm, Cm, Df, bf, state))
+            sets.append((u, delta, Af, Bm, Cm, Df, bf, state, out))
             outs.append(out)
         L.check(lib.cad_scan_fwd_multi(args, nsets, stream), "cad_scan_fwd_multi")
         flat = [t for s_ in sets for t in s_]
@@ -206,7 +206,7 @@ class _ScanMulti(torch.autograd.Function):
         args = (L.ScanBwdArgs * nsets)()
         keep, res = [], []
         for i in range(nsets):
-            u, delta, Af, Bm, Cm, Df, bf, state = flat[8 * i:8 * i + 8]
+            u, delta, Af, Bm, Cm, Df, bf, state, fout = flat[9 * i:9 * i + 9]
             E, SB, Lq = u.shape
             N = Af.shape[1]
             dout = douts[i].contiguous()
@@ -214,11 +214,11 @@ class _ScanMulti(torch.autograd.Function):
             dz = None if z is None else torch.empty_like(u)
             dA, dD, dbias = torch.zeros_like(Af), torch.zeros_like(Df), torch.zeros_like(bf)
             npart = lib.cad_scan_bwd_partials(E)  # one fp32 partial-sum slot per workgroup (written, not accumulated)
-            dBC = torch.empty((2, npart, N, SB, Lq), dtype=torch.float32, device=u.device)
+            dBC = torch.empty((2, npart, N, SB, Lq), dtype=u.dtype, device=u.device)
             stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dBC, dD, dbias)
             rl, rh = dirs[i]
             args[i] = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
-                                    L.ptr(bf), L.ptr(dout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz),
+                                    L.ptr(bf), L.ptr(dout), L.ptr(fout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz),
                                     L.ptr(dA), L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
                                     rl, rh, L.dtype_code(u.dtype), npart)
             keep.append((dout, dBC))
@@ -228,7 +228,7 @@ class _ScanMulti(torch.autograd.Function):
         dz_tot = None
         for i in range(nsets):
             du, ddelta, dA, dBC, dD, dbias, dz = res[i]
-            u = flat[8 * i]
+            u = flat[9 * i]
             n = dBC[0, 0].numel()
             npart = dBC.shape[1]
             dB, dC = torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device), \

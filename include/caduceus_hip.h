@@ -194,9 +194,12 @@ int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream);
 int64_t cad_scan_chunk_len(void);
 int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
 /* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E) are ACCUMULATED with a few fp32
- * atomics per channel (caller zeroes).  dB, dC: n_partials = cad_scan_bwd_partials(E) fp32 slots of (N,SB,L) each;
+ * atomics per channel (caller zeroes).  dB, dC: n_partials = cad_scan_bwd_partials(E) slots of (N,SB,L) each, in the
+ * activation dtype (fp32 mode: fp32 slots; bf16 mode: bf16 slots, each holding an fp32-accumulated 8-channel sum);
  * slot k is WRITTEN (plain coalesced stores, no atomics, no zeroing needed) with the sum over the channels of workgroup
- * k; cad_reduce_partials folds the slots into the final (N,SB,L) gradient.  chunk_state: as written by the forward. */
+ * k; cad_reduce_partials folds the slots (fp32 accumulation) into the final (N,SB,L) gradient.
+ * chunk_state: as written by the forward.  out: the forward's (gated) output, required when z != NULL: the gate gradient
+ * uses y = out / silu(z) instead of re-accumulating y (dz is 0 where z == 0 exactly). */
 typedef struct {
     const void* u;
     const void* delta;
@@ -207,13 +210,14 @@ typedef struct {
     const void* z;
     const float* delta_bias;
     const void* dout;
+    const void* out;
     const float* chunk_state;
     void* du;
     void* ddelta;
     void* dz;
     float* dA;
-    float* dB;
-    float* dC;
+    void* dB;
+    void* dC;
     float* dD;
     float* ddelta_bias;
     int64_t SB, L, split;
@@ -225,8 +229,8 @@ typedef struct {
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
 int cad_scan_bwd_partials(int E);
-/* dst[i] = sum_k src[k*n + i], k < n_partials; dst in dst_dtype (fp32 or bf16). */
-int cad_reduce_partials(const float* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream);
+/* dst[i] = sum_k src[k*n + i], k < n_partials (fp32 accumulation); src and dst in dtype (fp32 or bf16). */
+int cad_reduce_partials(const void* src, int n_partials, int64_t n, void* dst, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()
