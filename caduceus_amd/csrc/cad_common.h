@@ -210,6 +210,13 @@ __device__ __forceinline__ float cad_readlane(float v, int l) {
 __device__ __forceinline__ int cad_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// compiler-only fence: keeps the scheduler from hoisting (LDS) loads across this point, which bounds live ranges
+__device__ __forceinline__ void cad_sched_fence() {
+#ifndef CAD_EMU
+    asm volatile("" ::: "memory");
+#endif
+}
+
 // ---- direction / index maps ----------------------------------------------------------------------------------
 // logical position p in [0, L) of a row <-> physical index along L
 __device__ __forceinline__ int64_t cad_phys(int64_t p, int64_t L, int rev) { return rev ? (L - 1 - p) : p; }

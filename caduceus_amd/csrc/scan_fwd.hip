@@ -63,13 +63,21 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float du[SC_S], dt[SC_S], y[SC_S];
         f32x2 dd[SC_S];  // (dt, dt * u)
+#ifndef SC_FWD_PREFETCH
+        if (c > 0) {
+            sc_load_raw<T, SC_S, VEC>(u_row, p0, L, rev, u_raw);
+            sc_load_raw<T, SC_S, VEC>(d_row, p0, L, rev, d_raw);
+        }
+#endif
         sc_unpack<T, SC_S>(u_raw, rev, du);
         sc_unpack<T, SC_S>(d_raw, rev, dt);
+#ifdef SC_FWD_PREFETCH
         if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
         if (c + 1 < nchunks) {
             sc_load_raw<T, SC_S, VEC>(u_row, p0 + SC_CHUNK, L, rev, u_raw);
             sc_load_raw<T, SC_S, VEC>(d_row, p0 + SC_CHUNK, L, rev, d_raw);
         }
+#endif
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const float dti = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             }
             const f32x2 newc = readlane2(PA * hin + PH, 63);
             if (lane == np) carry = newc;
+            cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const f32x2 h = ha[i] * h0 + hh[i];
@@ -134,6 +143,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
         }
         if (z_row) {
             float zz[SC_S];
+#ifndef SC_FWD_PREFETCH
+            sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
+#endif
             sc_unpack<T, SC_S>(z_raw, rev, zz);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) y[i] *= zz[i] * cad_sigmoid(zz[i]);
