@@ -218,39 +218,44 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
             if (more) sc_stage_store<T, SC_S>(st, smem + (buf ^ 1) * 2 * TILE, rev);
             __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
-            // sum the SC_W regions and flush: thread t owns tensor t>>8, state (t>>7)&1 and 4 consecutive positions, i.e.
-            // one 16-byte store.  The next pair writes the other slab buffer, so one barrier per pair suffices.
+            // sum the SC_W regions and flush: thread t owns tensor t>>8, state (t>>7)&1 and FT consecutive positions,
+            // stored 4 at a time (8/16-byte stores).  The next pair writes the other slab buffer, so one barrier per
+            // pair suffices.
             {
+                constexpr int FT = SC_CHUNK / 128;  // positions per thread (4 or 8)
                 const int t = threadIdx.x;
                 const int s = (t >> 7) & 1;
                 const float* tile = acc + buf * ACC_BUF + (t >> 8) * ACC_TILE;
                 T* grow = ((t >> 8) ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
-                const int tok = (t & 127) * 4;
-                const int j = tok / SC_S, i0 = tok % SC_S;
-                float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float* src = tile + (i0 + q) * 128 + j * 2 + s;
-                    float sum = 0.f;
+                for (int h4 = 0; h4 < FT; h4 += 4) {
+                    const int tok = (t & 127) * FT + h4;
+                    const int j = tok / SC_S, i0 = tok % SC_S;
+                    float v[4];
 #pragma unroll
-                    for (int w = 0; w < SC_W; ++w) sum += src[w * 2 * ACC_TILE];
-                    v[q] = sum;
-                }
-                if (n0 + s < N) {
-                    const int64_t p = base + tok;
-                    if (VEC) {
-                        if (p < L) {
-                            if (rev) {
-                                const float o[4] = {v[3], v[2], v[1], v[0]};
-                                cad_cvt_store<T, 4>(grow + (L - p - 4), o);
-                            } else {
-                                cad_cvt_store<T, 4>(grow + p, v);
+                    for (int q = 0; q < 4; ++q) {
+                        const float* src = tile + (i0 + q) * 128 + j * 2 + s;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < SC_W; ++w) sum += src[w * 2 * ACC_TILE];
+                        v[q] = sum;
+                    }
+                    if (n0 + s < N) {
+                        const int64_t p = base + tok;
+                        if (VEC) {
+                            if (p < L) {
+                                if (rev) {
+                                    const float o[4] = {v[3], v[2], v[1], v[0]};
+                                    cad_cvt_store<T, 4>(grow + (L - p - 4), o);
+                                } else {
+                                    cad_cvt_store<T, 4>(grow + p, v);
+                                }
                             }
-                        }
-                    } else {
+                        } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (p + q < L) grow[cad_phys(p + q, L, rev)] = from_f32<T>(v[q]);
+                            for (int q = 0; q < 4; ++q)
+                                if (p + q < L) grow[cad_phys(p + q, L, rev)] = from_f32<T>(v[q]);
+                        }
                     }
                 }
             }

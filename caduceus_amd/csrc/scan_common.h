@@ -34,7 +34,7 @@
 #ifndef SC_OCC
 #define SC_OCC 2                // register budget: waves per SIMD the kernels are compiled for
 #endif
-#define SC_STATE_STEP 512
+#define SC_STATE_STEP (64 * SC_S_BWD)   // positions between saved running states = the backward's chunk
 #define SC_NMAX 64              // max d_state
 #define SC_MAXSETS 2
 #define SC_ROW(S) (2 * (S) + 4)        // floats per lane row of a B/C tile (S x float2 + 16 B pad -> conflict-free b128)
