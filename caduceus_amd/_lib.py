@@ -72,6 +72,13 @@ class ScanBwdArgs(C.Structure):
                 ("n_partials", _i)]
 
 
+class ScanTmArgs(C.Structure):
+    _fields_ = [("u", _p), ("delta", _p), ("z", _p), ("A", _p), ("BC", _p), ("D", _p), ("delta_bias", _p), ("out", _p),
+                ("state", _p), ("scratch", _p), ("SB", _i64), ("L", _i64), ("split", _i64), ("ld_u", _i64),
+                ("ld_delta", _i64), ("ld_z", _i64), ("ld_bc", _i64), ("ld_out", _i64), ("E", _i), ("N", _i),
+                ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
+
+
 class LmHeadArgs(C.Structure):
     _fields_ = [("hidden", _p), ("weight", _p), ("comp", _p), ("labels", _p), ("logits", _p), ("loss_sum", _p),
                 ("count", _p), ("rows", _i64), ("D", _i), ("V", _i), ("n_strands", _i), ("ignore_index", _i64),
@@ -97,6 +104,11 @@ SYMBOLS = {
     "cad_scan_bwd_multi": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_reduce_partials": (_i, [_p, _i, _i64, _p, _i, _p]),
     "cad_scan_bwd_partials": (_i, [_i]),
+    "cad_scan_tm_fwd": (_i, [C.POINTER(ScanTmArgs), _p]),
+    "cad_scan_tm_fwd_multi": (_i, [C.POINTER(ScanTmArgs), _i, _p]),
+    "cad_scan_tm_block_len": (_i64, []),
+    "cad_scan_tm_state_floats": (_i64, [_i, _i64, _i64, _i]),
+    "cad_scan_tm_scratch_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_prof_enable": (_i, [_i]),
     "cad_prof_reset": (_i, []),
@@ -165,8 +177,9 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream_and_check(*tensors):
-    """Validates device placement against the loaded library flavour and returns the launch stream handle."""
+def stream_and_check(*tensors, contiguous=True):
+    """Validates device placement against the loaded library flavour and returns the launch stream handle.
+    contiguous=False: the caller passes explicit row strides to the kernel (token-major column slices)."""
     dev_build = is_device_build()
     ref = None
     for t in tensors:
@@ -180,7 +193,7 @@ def stream_and_check(*tensors):
             ref = t
         elif t.device != ref.device:
             raise RuntimeError("caduceus_amd: all tensors of one op must be on the same device")
-        if not t.is_contiguous():
+        if contiguous and not t.is_contiguous():
             raise RuntimeError("caduceus_amd: kernel arguments must be contiguous")
     if dev_build:
         return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)

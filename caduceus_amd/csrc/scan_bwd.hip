@@ -29,9 +29,12 @@ struct ScanBwdSets {
 #define SC_CHUNK (64 * SC_S)
 #define ACC_TILE (SC_S * 64 * 2)        // floats per (wave, tensor) region, layout [item i][lane j][state s]
 #define ACC_BUF (SC_W * 2 * ACC_TILE)  // floats per buffer: [wave][dB,dC][ACC_TILE]
+#ifndef SC_SLAB_BUFS
+#define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
+#endif
 
 static_assert(SC_CHUNK == SC_STATE_STEP, "backward chunk = one saved-state slot");
-static_assert(64 * SC_W == 512, "the flush mapping below assumes 512 threads");
+static_assert(SC_W == 4 || SC_W == 8, "staging needs >= 256 threads; the flush mapping is written for 256 / 512");
 
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1])); }
 
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
-            float* aB = acc + buf * ACC_BUF + wave * 2 * ACC_TILE + lane * 2;  // (i, s) at aB[i * 128 + s]: 8-byte stride
+            float* aB = acc + (SC_SLAB_BUFS == 2 ? buf : 0) * ACC_BUF + wave * 2 * ACC_TILE + lane * 2;  // (i, s) at aB[i * 128 + s]: 8-byte stride
             float* aC = aB + ACC_TILE;
             const int n0 = 2 * np;
             const f32x2 Av = readlane2(Areg, np);
@@ -218,18 +221,19 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
             if (more) sc_stage_store<T, SC_S>(st, smem + (buf ^ 1) * 2 * TILE, rev);
             __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
-            // sum the SC_W regions and flush: thread t owns tensor t>>8, state (t>>7)&1 and FT consecutive positions,
-            // stored 4 at a time (8/16-byte stores).  The next pair writes the other slab buffer, so one barrier per
-            // pair suffices.
+            // sum the SC_W regions and flush: thread t owns one tensor (dB / dC), one state of the pair and FT
+            // consecutive positions, stored 4 at a time (8/16-byte stores).  With two slab buffers the next pair writes
+            // the other buffer, so one barrier per pair suffices.
             {
-                constexpr int FT = SC_CHUNK / 128;  // positions per thread (4 or 8)
+                constexpr int QT = 64 * SC_W / 4;     // threads per (tensor, state)
+                constexpr int FT = SC_CHUNK / QT;     // positions per thread (4 or 8)
                 const int t = threadIdx.x;
-                const int s = (t >> 7) & 1;
-                const float* tile = acc + buf * ACC_BUF + (t >> 8) * ACC_TILE;
-                T* grow = ((t >> 8) ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
+                const int ten = t / (2 * QT), s = (t / QT) & 1, idx = t % QT;
+                const float* tile = acc + (SC_SLAB_BUFS == 2 ? buf : 0) * ACC_BUF + ten * ACC_TILE;
+                T* grow = (ten ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
 #pragma unroll
                 for (int h4 = 0; h4 < FT; h4 += 4) {
-                    const int tok = (t & 127) * FT + h4;
+                    const int tok = idx * FT + h4;
                     const int j = tok / SC_S, i0 = tok % SC_S;
                     float v[4];
 #pragma unroll
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     }
                 }
             }
+            if (SC_SLAB_BUFS == 1) __syncthreads();  // the slab is rewritten by the next pair
         }
         // per-item outputs of this chunk (delta / z / dout are re-read: still L2-resident, keeps VGPRs free)
         float dl[SC_S];
@@ -372,7 +377,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
                       16) == 0;
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + 2 * ACC_BUF) * sizeof(float);
+    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + SC_SLAB_BUFS * ACC_BUF) * sizeof(float);
     if (a->dtype == CAD_F32) {
         if (vec)
             CAD_LAUNCH((scan_bwd_kernel<float, true>), grid, block, shmem, stream, ks);

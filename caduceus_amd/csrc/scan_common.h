@@ -78,13 +78,15 @@ __device__ __forceinline__ float wave_sum1(float v) {
     return v;
 }
 
-// wave-wide sum, result valid in EVERY lane: DPP row reduction (4 steps) + 4 v_readlane, no LDS traffic
+// wave-wide sum, result uniform (SGPR): DPP row reduction (4 steps) + 2 row broadcasts, then one v_readlane of lane 63
 __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_row_shr<1>(0.f, v);
     v += dpp_row_shr<2>(0.f, v);
     v += dpp_row_shr<4>(0.f, v);
     v += dpp_row_shr<8>(0.f, v);  // lane 15 of each row now holds its row total
-    return (cad_readlane(v, 15) + cad_readlane(v, 31)) + (cad_readlane(v, 47) + cad_readlane(v, 63));
+    v += dpp_row_bcast15(0.f, v);  // lanes 31 / 63: rows 0+1 / rows 2+3
+    v += dpp_row_bcast31(0.f, v);  // lane 63: everything
+    return cad_readlane(v, 63);
 }
 
 // One Kogge-Stone step of the affine-map scan: (A, H) <- (A, H) o (ua, uh) where (ua, uh) is the partner's map
@@ -97,24 +99,65 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
         A = A * ua_;                         \
     } while (0)
 
+#ifndef CAD_EMU
+// The same step with the DPP shift folded into the arithmetic (VOP2 + DPP, 4 instructions for a float2 map instead of
+// 4 v_mov + 4 v_mov_dpp + 2 v_pk): a lane whose DPP source does not exist (or whose row is masked off) is simply not
+// written, which IS the identity.  fmac before mul: H needs the old A.  Four instructions separate every DPP read from
+// the write of the same register (>= the 2 wait states the hardware requires); the leading s_nop covers the
+// compiler-generated producer of the inputs.
+#define SC_KS_ASM(CTRL)                          \
+    "v_fmac_f32_dpp %0, %0, %2 " CTRL "\n\t"     \
+    "v_fmac_f32_dpp %1, %1, %3 " CTRL "\n\t"     \
+    "v_mul_f32_dpp %2, %2, %2 " CTRL "\n\t"      \
+    "v_mul_f32_dpp %3, %3, %3 " CTRL "\n\t"
+#endif
+
 // Inclusive scan in lane order (lane 0 first).  On return (A, H) of lane j is the composition of lanes 0..j.
 __device__ __forceinline__ void wave_scan_fwd(f32x2& A, f32x2& H) {
+#ifdef CAD_EMU
     SC_COMBINE(A, H, dpp_row_shr<1>(1.f, A[0]), dpp_row_shr<1>(1.f, A[1]), dpp_row_shr<1>(0.f, H[0]), dpp_row_shr<1>(0.f, H[1]));
     SC_COMBINE(A, H, dpp_row_shr<2>(1.f, A[0]), dpp_row_shr<2>(1.f, A[1]), dpp_row_shr<2>(0.f, H[0]), dpp_row_shr<2>(0.f, H[1]));
     SC_COMBINE(A, H, dpp_row_shr<4>(1.f, A[0]), dpp_row_shr<4>(1.f, A[1]), dpp_row_shr<4>(0.f, H[0]), dpp_row_shr<4>(0.f, H[1]));
     SC_COMBINE(A, H, dpp_row_shr<8>(1.f, A[0]), dpp_row_shr<8>(1.f, A[1]), dpp_row_shr<8>(0.f, H[0]), dpp_row_shr<8>(0.f, H[1]));
     SC_COMBINE(A, H, dpp_row_bcast15(1.f, A[0]), dpp_row_bcast15(1.f, A[1]), dpp_row_bcast15(0.f, H[0]), dpp_row_bcast15(0.f, H[1]));
     SC_COMBINE(A, H, dpp_row_bcast31(1.f, A[0]), dpp_row_bcast31(1.f, A[1]), dpp_row_bcast31(0.f, H[0]), dpp_row_bcast31(0.f, H[1]));
+#else
+    float h0 = H[0], h1 = H[1], a0 = A[0], a1 = A[1];
+    asm("s_nop 1\n\t"
+        SC_KS_ASM("row_shr:1 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_shr:4 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_shr:8 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        SC_KS_ASM("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(h0), "+v"(h1), "+v"(a0), "+v"(a1));
+    H = f2(h0, h1);
+    A = f2(a0, a1);
+#endif
 }
 
 // Inclusive scan in REVERSE lane order (lane 63 first): (A, G) of lane j is the composition of lanes 63..j.
 // Row-local steps use DPP row_shl; the two cross-row steps have no DPP broadcast in this direction and go through
 // ds_bpermute (__shfl) / readlane.
 __device__ __forceinline__ void wave_scan_rev(f32x2& A, f32x2& G, int lane) {
+#ifdef CAD_EMU
     SC_COMBINE(A, G, dpp_row_shl<1>(1.f, A[0]), dpp_row_shl<1>(1.f, A[1]), dpp_row_shl<1>(0.f, G[0]), dpp_row_shl<1>(0.f, G[1]));
     SC_COMBINE(A, G, dpp_row_shl<2>(1.f, A[0]), dpp_row_shl<2>(1.f, A[1]), dpp_row_shl<2>(0.f, G[0]), dpp_row_shl<2>(0.f, G[1]));
     SC_COMBINE(A, G, dpp_row_shl<4>(1.f, A[0]), dpp_row_shl<4>(1.f, A[1]), dpp_row_shl<4>(0.f, G[0]), dpp_row_shl<4>(0.f, G[1]));
     SC_COMBINE(A, G, dpp_row_shl<8>(1.f, A[0]), dpp_row_shl<8>(1.f, A[1]), dpp_row_shl<8>(0.f, G[0]), dpp_row_shl<8>(0.f, G[1]));
+#else
+    {
+        float g0 = G[0], g1 = G[1], a0 = A[0], a1 = A[1];
+        asm("s_nop 1\n\t"
+            SC_KS_ASM("row_shl:1 row_mask:0xf bank_mask:0xf")
+            SC_KS_ASM("row_shl:2 row_mask:0xf bank_mask:0xf")
+            SC_KS_ASM("row_shl:4 row_mask:0xf bank_mask:0xf")
+            SC_KS_ASM("row_shl:8 row_mask:0xf bank_mask:0xf")
+            : "+v"(g0), "+v"(g1), "+v"(a0), "+v"(a1));
+        G = f2(g0, g1);
+        A = f2(a0, a1);
+    }
+#endif
     // after the row-local steps the FIRST lane of every row holds its whole row; fold the later rows in
     {   // rows 0 and 2 <- total of the next row
         const int src = (((lane >> 4) + 1) << 4) & 63;

@@ -257,6 +257,48 @@ def selective_scan(u, delta, A, Bm, Cm, D, z, delta_bias, split: int, rev_lo: in
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# selective scan, token-major kernels
+# ------------------------------------------------------------------------------------------------------------------
+def scan_tm_forward(sets, z, split: int, dirs, save_state: bool = True):
+    """Raw (no autograd) token-major forward for 1 or 2 parameter sets in one launch sequence.
+    sets: list of (u, delta, A, BC, D, delta_bias) with u, delta: (SB, L, E) views whose last dim is contiguous (row
+    stride free), BC: fp32 (SB, L, >= 2N) view holding B_t | C_t in its first 2N columns, A: (E, N).
+    z: (SB, L, E) view or None (shared gate).  Returns [(out, state, scratch)] per set."""
+    lib = L.get_lib()
+    nsets = len(sets)
+    args = (L.ScanTmArgs * nsets)()
+    res, keep = [], []
+
+    def _ld(t):
+        ld = t.stride(1) if t.shape[1] > 1 else max(t.stride(1), t.shape[2])  # size-1 dims carry arbitrary strides
+        if t.stride(-1) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld):
+            raise ValueError("scan_tm: activations must be (SB, L, E) views with unit channel stride and dense rows")
+        return ld
+
+    for i, (u, delta, A, BC, D, bias) in enumerate(sets):
+        SB, Lq, E = u.shape
+        N = A.shape[1]
+        if delta.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
+            raise TypeError("scan_tm: u, delta, z must share one dtype")
+        if BC.dtype != torch.float32:
+            raise TypeError("scan_tm: BC must be fp32")
+        Af, Df, bf = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
+        out = torch.empty((SB, Lq, E), dtype=u.dtype, device=u.device)
+        state = (torch.empty((lib.cad_scan_tm_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
+                 if save_state else None)
+        scratch = torch.empty((lib.cad_scan_tm_scratch_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
+        stream = L.stream_and_check(u, delta, z, Af, BC, Df, bf, out, state, scratch, contiguous=False)
+        rl, rh = dirs[i]
+        args[i] = L.ScanTmArgs(L.ptr(u), L.ptr(delta), L.ptr(z), L.ptr(Af), L.ptr(BC), L.ptr(Df), L.ptr(bf), L.ptr(out),
+                               L.ptr(state), L.ptr(scratch), SB, Lq, split, _ld(u), _ld(delta),
+                               0 if z is None else _ld(z), _ld(BC), _ld(out), E, N, rl, rh, L.dtype_code(u.dtype))
+        keep.append((Af, Df, bf))
+        res.append((out, state, scratch))
+    L.check(lib.cad_scan_tm_fwd_multi(args, nsets, stream), "cad_scan_tm_fwd_multi")
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # LM head (+ masked cross entropy)
 # ------------------------------------------------------------------------------------------------------------------
 class _LmHead(torch.autograd.Function):

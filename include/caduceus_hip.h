@@ -233,6 +233,45 @@ int cad_scan_bwd_partials(int E);
 int cad_reduce_partials(const void* src, int n_partials, int64_t n, void* dst, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Selective SSM scan, TOKEN-MAJOR ("tm") kernels: same mathematics and the same reference call sites as
+ * cad_scan_fwd / cad_scan_bwd above (selective_scan_cuda.fwd/.bwd behind mamba_ssm.Mamba.forward,
+ * modeling_caduceus.py:128,130), for activations laid out (SB, L, E) with E contiguous -- the layout the in_proj /
+ * dt_proj GEMMs write and out_proj reads without any transpose.  One lane owns one or two channels and walks its
+ * chunk sequentially with all N states in registers (no cross-lane scan, no LDS); B_t / C_t are wave-uniform and are
+ * fetched with scalar loads.
+ *   u, delta, z, out : (SB, L, E) dtype, row strides ld_* in ELEMENTS (z / u may be column slices of the
+ *                      in_proj output, ld = 2E).
+ *   BC               : fp32 (SB, L, ld_bc): columns [0, N) = B_t, [N, 2N) = C_t (the fp32 x_proj output, offset
+ *                      by dt_rank columns).
+ *   state            : fp32 [SB][ceil(L / cad_scan_tm_block_len())][N][E]: the running state entering every
+ *                      block, written by the forward for the backward (NULL: not saved).
+ *   scratch          : fp32, cad_scan_tm_scratch_floats() elements: per-chunk aggregates, then chunk-start states.
+ * Rows [0, split) run in direction rev_lo, rows [split, SB) in rev_hi, as an exact mirror (bit-exact
+ * RC-equivariance). */
+typedef struct {
+    const void* u;
+    const void* delta;
+    const void* z;
+    const float* A;
+    const float* BC;
+    const float* D;
+    const float* delta_bias;
+    void* out;
+    float* state;
+    float* scratch;
+    int64_t SB, L, split;
+    int64_t ld_u, ld_delta, ld_z, ld_bc, ld_out;
+    int E, N;
+    int rev_lo, rev_hi;
+    int dtype;
+} cad_scan_tm_args;
+int cad_scan_tm_fwd(const cad_scan_tm_args* a, void* stream);
+int cad_scan_tm_fwd_multi(const cad_scan_tm_args* sets, int nsets, void* stream);
+int64_t cad_scan_tm_block_len(void);
+int64_t cad_scan_tm_state_floats(int E, int64_t SB, int64_t L, int N);
+int64_t cad_scan_tm_scratch_floats(int E, int64_t SB, int64_t L, int N);
+
+/* ---------------------------------------------------------------------------------------------------------
  * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()
  * (modeling_caduceus.py:475) and cross_entropy(ignore_index) (modeling_caduceus.py:279-283,
  * src/tasks/metrics.py:181-184).  t-frame:  logits[b,l,v] = <W[v], t1[b,l]> + <W[comp[v]], t2[b,l]>.

@@ -217,3 +217,59 @@ def test_lm_head_and_loss(backend, n_strands, dtype):
     torch.testing.assert_close(loss.cpu(), rloss.detach(), **FP32)
     torch.testing.assert_close(hd.grad.float().cpu(), rh.grad, **tol)
     torch.testing.assert_close(wd.grad.cpu(), rw.grad, rtol=tol["rtol"], atol=tol["atol"])
+
+
+# ---- token-major scan kernels ------------------------------------------------------------------------------------------
+TM_CASES = [  # E, SB, L, N, split, rev_lo, rev_hi
+    (4, 1, 64, 16, 1, 0, 0),
+    (6, 2, 100, 16, 1, 0, 1),
+    (3, 2, 37, 8, 1, 1, 0),
+    (5, 1, 1100, 16, 0, 0, 1),
+    (2, 1, 1, 3, 1, 0, 0),
+    (10, 3, 2064, 16, 2, 1, 0),
+    (8, 2, 600, 20, 1, 0, 1),
+]
+
+
+def _tm(t):  # channel-major (E, SB, L) -> token-major (SB, L, E)
+    return t.permute(1, 2, 0).contiguous()
+
+
+@pytest.mark.parametrize("case", TM_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sliced", [False, True])
+def test_scan_tm_forward(backend, case, dtype, sliced):
+    """Token-major forward (cad_scan_tm_fwd_multi) vs the oracle; `sliced` passes u / z as column slices of one
+    (SB, L, 2E) buffer and B|C as a column slice of a wider fp32 buffer, as the mixer does."""
+    name, dev = backend
+    E, SB, L, N, split, rl, rh = case
+    t = _scan_inputs(E, SB, L, N, 23, dev, dtype)
+    u, delta, z = (_tm(t[k]).to(dev).to(dtype) for k in ("u", "delta", "z"))
+    BC = torch.cat([_tm(t["B"]), _tm(t["C"])], -1).to(dev)  # (SB, L, 2N) fp32
+    if sliced:
+        xz = torch.cat([u, z], -1).contiguous()
+        u, z = xz[..., :E], xz[..., E:]
+        wide = torch.cat([torch.zeros(SB, L, 4, device=dev), BC], -1).contiguous()
+        BC = wide[..., 4:]
+    A, D, bias = t["A"].to(dev), t["D"].to(dev), t["bias"].to(dev)
+    (out, state, _), = ops.scan_tm_forward([(u, delta, A, BC, D, bias)], z, split, [(rl, rh)])
+    ref = _rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, t["A"], B_, C_, t["D"], z_, t["bias"]),
+                       [t["u"], t["delta"], t["B"], t["C"], t["z"]], split, rl, rh)
+    tol = FP32 if dtype == torch.float32 else BF16
+    torch.testing.assert_close(out.float().cpu(), _tm(ref), **tol)
+    assert torch.isfinite(state).all()
+
+
+def test_scan_tm_forward_two_sets_mirror(backend):
+    """Two parameter sets in one launch, and the mirror property: a right-to-left row on flipped data is bit-identical
+    to the left-to-right row."""
+    name, dev = backend
+    E, SB, L, N = 6, 2, 1300, 16
+    t = _scan_inputs(E, SB, L, N, 5, dev, torch.float32)
+    u, delta, z = (_tm(t[k]).to(dev) for k in ("u", "delta", "z"))
+    BC = torch.cat([_tm(t["B"]), _tm(t["C"])], -1).to(dev)
+    A, D, bias = t["A"].to(dev), t["D"].to(dev), t["bias"].to(dev)
+    f = lambda x: x.flip(1).contiguous()
+    r = ops.scan_tm_forward([(u, delta, A, BC, D, bias), (f(u), f(delta), A, f(BC), D, bias)], None, SB, [(0, 0), (1, 1)])
+    assert torch.equal(r[0][0], f(r[1][0]))
+    assert torch.equal(r[0][1], r[1][1])  # saved states are indexed by logical position

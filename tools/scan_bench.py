@@ -9,7 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from caduceus_amd import ops  # noqa: E402
+from caduceus_amd import ops, _lib  # noqa: E402
 
 
 def timeit(fn, reps):
@@ -76,7 +76,11 @@ def main():
 
     def bwd2():
         torch.autograd.backward([o1, o2], [g1, g2], retain_graph=True)
+    _lib.prof_reset(); _lib.prof_enable(True)
     t = timeit(bwd2, a.reps)
+    _lib.prof_enable(False)
+    pr = _lib.prof_read()
+    res["scan_bwd2_kernel_ms"] = pr["scan_bwd"][0] / max(1, pr["scan_bwd"][1])
     res["scan_bwd2_ms"] = t
     res["scan_bwd2_GBps"] = 2 * (7 * E + 4 * N) * s * T / t / 1e6
     if a.only_scan:
