@@ -96,6 +96,8 @@ SYMBOLS = {
     "cad_add_norm_bwd": (_i, [C.POINTER(AddNormBwdArgs), _p]),
     "cad_conv1d_fwd": (_i, [C.POINTER(Conv1dArgs), _p]),
     "cad_conv1d_bwd": (_i, [C.POINTER(Conv1dBwdArgs), _p]),
+    "cad_conv1d_fwd_multi": (_i, [C.POINTER(Conv1dArgs), _i, _p]),
+    "cad_conv1d_bwd_multi": (_i, [C.POINTER(Conv1dBwdArgs), _i, _p]),
     "cad_scan_fwd": (_i, [C.POINTER(ScanArgs), _p]),
     "cad_scan_chunk_len": (_i64, []),
     "cad_scan_state_floats": (_i64, [_i, _i64, _i64, _i]),

@@ -33,6 +33,7 @@
 
 // ---- small numeric helpers ---------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((vector_size(8)));  // maps to v_pk_{mul,fma,add}_f32 on gfx950
+typedef float f32x4 __attribute__((vector_size(16)));
 
 struct bf16_t {
     uint16_t v;
@@ -97,6 +98,16 @@ template <>
 __device__ __forceinline__ void cad_cvt_store<bf16_t, 4>(bf16_t* dst, const float* v) {
     struct __attribute__((aligned(8))) V { uint32_t w[2]; } t = {{cad_pack_bf16x2(v[0], v[1]), cad_pack_bf16x2(v[2], v[3])}};
     *(V*)dst = t;
+}
+
+template <>
+__device__ __forceinline__ void cad_cvt_store<float, 2>(float* dst, const float* v) {
+    struct __attribute__((aligned(8))) V { float f[2]; } t = {{v[0], v[1]}};
+    *(V*)dst = t;
+}
+template <>
+__device__ __forceinline__ void cad_cvt_store<bf16_t, 2>(bf16_t* dst, const float* v) {
+    *(uint32_t*)dst = cad_pack_bf16x2(v[0], v[1]);
 }
 
 #define CAD_LOG2E 1.4426950408889634f

@@ -1,202 +1,326 @@
-// Depthwise causal conv1d (+bias +SiLU) along L on channel-major (E, SB, L) activations, with a per-row
-// direction map (include/caduceus_hip.h, cad_conv1d_*).  HBM-bound: each thread produces 8 consecutive logical
-// positions from one 16-byte (bf16) / 32-byte (fp32) vector plus its predecessor (halo through L1).
+// Depthwise causal conv1d (+bias +SiLU) along L on channel-major (E, SB, L) activations, with a per-row direction
+// map (include/caduceus_hip.h, cad_conv1d_*).  HBM-bound streaming kernels.
+//
+// A lane owns 8 consecutive PHYSICAL positions (one 16-byte bf16 / 32-byte fp32 vector); the 3-position halos on both
+// sides come from the neighbouring lanes through DPP wave shifts, so every element of x / dout is loaded exactly once.
+// Lanes 0 and 63 of a wave are halo lanes (they load and pre-compute but do not store), i.e. a wave produces 62 * 8 =
+// 496 positions.  Working in physical order makes the direction a choice of taps instead of an index map: a row that
+// runs left-to-right uses the taps on its left, a right-to-left row the mirrored taps on its right, expressed as one
+// 7-tap window W7 around the position with the unused taps set to zero.
+// Up to two parameter sets that read the SAME x (mamba_fwd / mamba_rev of a BiMamba layer, which see the same in_proj
+// output in opposite directions) run in one launch: x is read once, and in the backward dx = dx_0 + dx_1 is written once.
 #include "cad_common.h"
 
 namespace {
 
 #define CV_VEC 8
-#define CV_THREADS 256
+#define CV_WAVES 4
+#define CV_THREADS (64 * CV_WAVES)
 #define CV_KMAX 4
+#define CV_TAPS (2 * CV_KMAX - 1)                 // 7-tap window: offsets -3 .. +3
+#define CV_HALO (CV_KMAX - 1)
+#define CV_WAVE_POS (62 * CV_VEC)                 // useful positions per wave tile
+#define CV_TILES_BWD 8                            // wave tiles a backward workgroup walks before reducing dw / dbias
+#define CV_MAXSETS 2
 
-// Load CV_VEC logical positions [p0, p0+8) of one row into out[0..7] (zeros outside [0, L)).
+struct ConvFwdSets {
+    cad_conv1d_args s[CV_MAXSETS];
+};
+struct ConvBwdSets {
+    cad_conv1d_bwd_args s[CV_MAXSETS];
+};
+
 template <typename T>
-__device__ __forceinline__ void load8(const T* row, int64_t p0, int64_t L, int rev, bool vec_ok, float* out) {
-    if (vec_ok && p0 >= 0 && p0 + CV_VEC <= L) {
-        const int64_t l0 = rev ? (L - p0 - CV_VEC) : p0;
-        typedef struct __attribute__((aligned(sizeof(T) * CV_VEC))) {
-            T v[CV_VEC];
-        } vec_t;
-        const vec_t tmp = *(const vec_t*)(row + l0);
+struct __attribute__((aligned(sizeof(T) * CV_VEC))) CvVec {
+    T v[CV_VEC];
+};
+
+// physical positions [l0, l0 + 8) of one row -> fp32, zeros outside [0, L)
+template <typename T>
+__device__ __forceinline__ void load8(const T* row, int64_t l0, int64_t L, bool vec_ok, float* out) {
+    if (vec_ok && l0 >= 0 && l0 + CV_VEC <= L) {
+        const CvVec<T> tmp = *(const CvVec<T>*)(row + l0);
 #pragma unroll
-        for (int j = 0; j < CV_VEC; ++j) out[j] = to_f32(tmp.v[rev ? (CV_VEC - 1 - j) : j]);
+        for (int j = 0; j < CV_VEC; ++j) out[j] = to_f32(tmp.v[j]);
     } else {
 #pragma unroll
         for (int j = 0; j < CV_VEC; ++j) {
-            const int64_t p = p0 + j;
-            out[j] = (p >= 0 && p < L) ? to_f32(row[cad_phys(p, L, rev)]) : 0.f;
+            const int64_t l = l0 + j;
+            out[j] = (l >= 0 && l < L) ? to_f32(row[l]) : 0.f;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* row, int64_t l0, int64_t L, bool vec_ok, const float* v) {
+    if (vec_ok && l0 >= 0 && l0 + CV_VEC <= L) {
+        CvVec<T> tmp;
+#pragma unroll
+        for (int j = 0; j < CV_VEC; ++j) tmp.v[j] = from_f32<T>(v[j]);
+        *(CvVec<T>*)(row + l0) = tmp;
+    } else {
+#pragma unroll
+        for (int j = 0; j < CV_VEC; ++j) {
+            const int64_t l = l0 + j;
+            if (l >= 0 && l < L) row[l] = from_f32<T>(v[j]);
         }
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void store8(T* row, int64_t p0, int64_t L, int rev, bool vec_ok, const float* v) {
-    if (vec_ok && p0 + CV_VEC <= L) {
-        const int64_t l0 = rev ? (L - p0 - CV_VEC) : p0;
-        typedef struct __attribute__((aligned(sizeof(T) * CV_VEC))) {
-            T v[CV_VEC];
-        } vec_t;
-        vec_t tmp;
+// own[8] -> window e[14] = 3 left-halo + 8 own + 3 right-halo values (neighbouring lanes; 0 at the wave edges)
+__device__ __forceinline__ void halo_window(const float* own, float* e) {
 #pragma unroll
-        for (int j = 0; j < CV_VEC; ++j) tmp.v[rev ? (CV_VEC - 1 - j) : j] = from_f32<T>(v[j]);
-        *(vec_t*)(row + l0) = tmp;
-    } else {
-#pragma unroll
-        for (int j = 0; j < CV_VEC; ++j) {
-            const int64_t p = p0 + j;
-            if (p < L) row[cad_phys(p, L, rev)] = from_f32<T>(v[j]);
-        }
+    for (int i = 0; i < CV_HALO; ++i) {
+        e[i] = dpp_wave_shr1(0.f, own[CV_VEC - CV_HALO + i]);
+        e[CV_HALO + CV_VEC + i] = dpp_wave_shl1(0.f, own[i]);
     }
+#pragma unroll
+    for (int j = 0; j < CV_VEC; ++j) e[CV_HALO + j] = own[j];
 }
 
-template <typename T>
-__global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(cad_conv1d_args a) {
+// taps of the forward conv of a row with direction `rev` inside the 7-tap window (offset m - 3):
+// left-to-right: out[l] = b + sum_k w[k] x[l - (K-1) + k];  right-to-left: out[l] = b + sum_k w[k] x[l + (K-1) - k]
+__device__ __forceinline__ int tap_index(int k, int K, int rev) { return rev ? (CV_HALO + (K - 1) - k) : (CV_HALO - (K - 1) + k); }
+
+// b + sum over the window; the taps are accumulated in the order k = 0 .. K-1 of the row's own direction (ascending
+// window index for left-to-right taps, descending for right-to-left ones), so a right-to-left row is the exact mirror
+// -- same floating-point operation order -- of a left-to-right row on flipped data (zero taps add exact zeros).
+__device__ __forceinline__ float conv7(const float* W, const float* win, float b, int descending) {
+    float acc = b;
+    if (descending) {
+#pragma unroll
+        for (int m = CV_TAPS - 1; m >= 0; --m) acc += W[m] * win[m];
+    } else {
+#pragma unroll
+        for (int m = 0; m < CV_TAPS; ++m) acc += W[m] * win[m];
+    }
+    return acc;
+}
+
+template <typename T, int NSETS>
+__global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets) {
+    const cad_conv1d_args& a0 = sets.s[0];
     const int64_t rowid = blockIdx.x;  // e * SB + sb
-    const int e = (int)(rowid / a.SB);
-    const int64_t sb = rowid - (int64_t)e * a.SB;
-    const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
-    const int64_t L = a.L;
-    const T* x = (const T*)a.x + rowid * L;
-    T* out = (T*)a.out + rowid * L;
-    const bool vec_ok = (L % CV_VEC) == 0 && (((uintptr_t)a.x | (uintptr_t)a.out) % (sizeof(T) * CV_VEC)) == 0;
-    float w[CV_KMAX];
+    const int e = (int)(rowid / a0.SB);
+    const int64_t sb = rowid - (int64_t)e * a0.SB;
+    const int64_t L = a0.L;
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const T* x = (const T*)a0.x + rowid * L;
+    bool vec_ok = (L % CV_VEC) == 0 && ((uintptr_t)a0.x % (sizeof(T) * CV_VEC)) == 0;
+    float W7[NSETS][CV_TAPS], bias[NSETS];
+    int revs[NSETS];
 #pragma unroll
-    for (int k = 0; k < CV_KMAX; ++k) w[k] = k < a.K ? a.w[e * a.K + k] : 0.f;
-    const float b = a.bias ? a.bias[e] : 0.f;
-    const int64_t p0 = ((int64_t)blockIdx.y * CV_THREADS + threadIdx.x) * CV_VEC;
-    if (p0 >= L) return;
-    float xs[2 * CV_VEC];
-    load8(x, p0 - CV_VEC, L, rev, vec_ok, xs);
-    load8(x, p0, L, rev, vec_ok, xs + CV_VEC);
-    float o[CV_VEC];
+    for (int s = 0; s < NSETS; ++s) {
+        const cad_conv1d_args& a = sets.s[s];
+        vec_ok = vec_ok && ((uintptr_t)a.out % (sizeof(T) * CV_VEC)) == 0;
+        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
+        revs[s] = rev;
 #pragma unroll
-    for (int j = 0; j < CV_VEC; ++j) {
-        float acc = b;
+        for (int m = 0; m < CV_TAPS; ++m) W7[s][m] = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            const int m = tap_index(k, a.K, rev);
+            const float wk = a.w[e * a.K + k];
 #pragma unroll
-        for (int k = 0; k < CV_KMAX; ++k)
-            if (k < a.K) acc += w[k] * xs[CV_VEC + j - (a.K - 1) + k];
-        o[j] = acc * cad_sigmoid(acc);
-    }
-    store8(out, p0, L, rev, vec_ok, o);
-}
-
-// Backward.  dpre[p] = dout[p] * silu'(pre[p]);  dx[q] = sum_k w[k] * dpre[q + (K-1) - k];
-// dw[k] = sum_p dpre[p] * x[p - (K-1) + k];  dbias = sum_p dpre[p].
-template <typename T>
-__global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(cad_conv1d_bwd_args a) {
-    __shared__ float red[CV_THREADS / 64][CV_KMAX + 1];
-    const int64_t rowid = blockIdx.x;
-    const int e = (int)(rowid / a.SB);
-    const int64_t sb = rowid - (int64_t)e * a.SB;
-    const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
-    const int64_t L = a.L;
-    const int K = a.K;
-    const T* x = (const T*)a.x + rowid * L;
-    const T* dout = (const T*)a.dout + rowid * L;
-    T* dx = (T*)a.dx + rowid * L;
-    const bool vec_ok =
-        (L % CV_VEC) == 0 && (((uintptr_t)a.x | (uintptr_t)a.dout | (uintptr_t)a.dx) % (sizeof(T) * CV_VEC)) == 0;
-    float w[CV_KMAX];
-#pragma unroll
-    for (int k = 0; k < CV_KMAX; ++k) w[k] = k < K ? a.w[e * K + k] : 0.f;
-    const float b = a.bias ? a.bias[e] : 0.f;
-    const int64_t p0 = ((int64_t)blockIdx.y * CV_THREADS + threadIdx.x) * CV_VEC;
-    float part[CV_KMAX + 1];
-#pragma unroll
-    for (int k = 0; k <= CV_KMAX; ++k) part[k] = 0.f;
-    if (p0 < L) {
-        float xs[3 * CV_VEC], gs[2 * CV_VEC];
-        load8(x, p0 - CV_VEC, L, rev, vec_ok, xs);
-        load8(x, p0, L, rev, vec_ok, xs + CV_VEC);
-        load8(x, p0 + CV_VEC, L, rev, vec_ok, xs + 2 * CV_VEC);
-        load8(dout, p0, L, rev, vec_ok, gs);
-        load8(dout, p0 + CV_VEC, L, rev, vec_ok, gs + CV_VEC);
-        // dpre at logical p0 .. p0 + 8 + (K-1) - 1
-        float dpre[CV_VEC + CV_KMAX - 1];
-#pragma unroll
-        for (int j = 0; j < CV_VEC + CV_KMAX - 1; ++j) {
-            float acc = b;
-#pragma unroll
-            for (int k = 0; k < CV_KMAX; ++k)
-                if (k < K) acc += w[k] * xs[CV_VEC + j - (K - 1) + k];
-            const float sg = cad_sigmoid(acc);
-            dpre[j] = (j < CV_VEC + K - 1 && p0 + j < L) ? gs[j] * sg * (1.f + acc * (1.f - sg)) : 0.f;
+            for (int mm = 0; mm < CV_TAPS; ++mm)
+                if (mm == m) W7[s][mm] = wk;
         }
+        bias[s] = a.bias ? a.bias[e] : 0.f;
+    }
+    const int64_t tile = (int64_t)blockIdx.y * CV_WAVES + wave;
+    const int64_t l0 = tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
+    if (tile * CV_WAVE_POS >= L) return;  // wave-uniform
+    float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO];
+    load8(x, l0, L, vec_ok, own);
+    halo_window(own, xe);
+    const bool useful = lane >= 1 && lane <= 62;
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) {
         float o[CV_VEC];
 #pragma unroll
         for (int j = 0; j < CV_VEC; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < CV_KMAX; ++k)
-                if (k < K) acc += w[k] * dpre[j + (K - 1) - k];
-            o[j] = acc;
-#pragma unroll
-            for (int k = 0; k < CV_KMAX; ++k)
-                if (k < K) part[k] += dpre[j] * xs[CV_VEC + j - (K - 1) + k];
-            part[CV_KMAX] += dpre[j];
+            const float acc = conv7(W7[s], xe + j, bias[s], revs[s]);
+            o[j] = acc * cad_sigmoid(acc);
         }
-        if (a.accumulate) {
-            float prev[CV_VEC];
-            load8(dx, p0, L, rev, vec_ok, prev);
+        if (useful) store8((T*)sets.s[s].out + rowid * L, l0, L, vec_ok, o);
+    }
+}
+
+// Backward.  dpre[l] = dout[l] * silu'(pre[l]);  dx = sum over the sets of the transposed conv of dpre (the taps of
+// the opposite direction);  dw[k] = sum_l dpre[l] * x[l + offset_k];  dbias = sum_l dpre[l].
+template <typename T, int NSETS>
+__global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets) {
+    __shared__ float red[CV_WAVES][NSETS][CV_TAPS + 1];
+    const cad_conv1d_bwd_args& a0 = sets.s[0];
+    const int64_t rowid = blockIdx.x;
+    const int e = (int)(rowid / a0.SB);
+    const int64_t sb = rowid - (int64_t)e * a0.SB;
+    const int64_t L = a0.L;
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const T* x = (const T*)a0.x + rowid * L;
+    T* dx = (T*)a0.dx + rowid * L;
+    bool vec_ok = (L % CV_VEC) == 0 && (((uintptr_t)a0.x | (uintptr_t)a0.dx) % (sizeof(T) * CV_VEC)) == 0;
+    float W7[NSETS][CV_TAPS], V7[NSETS][CV_TAPS], bias[NSETS], part[NSETS][CV_TAPS + 1];
+    int revs[NSETS];
 #pragma unroll
-            for (int j = 0; j < CV_VEC; ++j) o[j] += prev[j];
+    for (int s = 0; s < NSETS; ++s) {
+        const cad_conv1d_bwd_args& a = sets.s[s];
+        vec_ok = vec_ok && ((uintptr_t)a.dout % (sizeof(T) * CV_VEC)) == 0;
+        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
+        revs[s] = rev;
+#pragma unroll
+        for (int m = 0; m < CV_TAPS; ++m) W7[s][m] = 0.f, V7[s][m] = 0.f;
+#pragma unroll
+        for (int m = 0; m <= CV_TAPS; ++m) part[s][m] = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            const int m = tap_index(k, a.K, rev), mt = tap_index(k, a.K, !rev);
+            const float wk = a.w[e * a.K + k];
+#pragma unroll
+            for (int mm = 0; mm < CV_TAPS; ++mm) {
+                if (mm == m) W7[s][mm] = wk;
+                if (mm == mt) V7[s][mm] = wk;
+            }
         }
-        store8(dx, p0, L, rev, vec_ok, o);
+        bias[s] = a.bias ? a.bias[e] : 0.f;
     }
-    // block reduction of dw / dbias partials
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float useful = (lane >= 1 && lane <= 62) ? 1.f : 0.f;
+    for (int it = 0; it < CV_TILES_BWD; ++it) {
+        const int64_t tile = ((int64_t)blockIdx.y * CV_TILES_BWD + it) * CV_WAVES + wave;
+        if (tile * CV_WAVE_POS >= L) break;  // wave-uniform
+        const int64_t l0 = tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
+        float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO], o[CV_VEC];
+        load8(x, l0, L, vec_ok, own);
+        halo_window(own, xe);
+        if (a0.accumulate) {
+            load8(dx, l0, L, vec_ok, o);
+        } else {
 #pragma unroll
-    for (int k = 0; k <= CV_KMAX; ++k) {
-        float v = part[k];
+            for (int j = 0; j < CV_VEC; ++j) o[j] = 0.f;
+        }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        if (lane == 0) red[wave][k] = v;
+        for (int s = 0; s < NSETS; ++s) {
+            float g[CV_VEC], dpre[CV_VEC], dpe[CV_VEC + 2 * CV_HALO];
+            load8((const T*)sets.s[s].dout + rowid * L, l0, L, vec_ok, g);
+#pragma unroll
+            for (int j = 0; j < CV_VEC; ++j) {
+                const float acc = conv7(W7[s], xe + j, bias[s], revs[s]);
+                const float sg = cad_sigmoid(acc);
+                dpre[j] = g[j] * sg * (1.f + acc * (1.f - sg));  // dout is 0 outside [0, L) -> so is dpre
+            }
+            halo_window(dpre, dpe);
+#pragma unroll
+            for (int j = 0; j < CV_VEC; ++j) {
+                o[j] += conv7(V7[s], dpe + j, 0.f, !revs[s]);  // transposed conv = the taps of the opposite direction
+                const float dm = dpre[j] * useful;  // halo lanes belong to the neighbouring tile
+#pragma unroll
+                for (int m = 0; m < CV_TAPS; ++m) part[s][m] += dm * xe[j + m];
+                part[s][CV_TAPS] += dm;
+            }
+        }
+        if (useful != 0.f) store8(dx, l0, L, vec_ok, o);
     }
+    // workgroup reduction of the dw / dbias partials, then a handful of atomics per workgroup
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+        for (int m = 0; m <= CV_TAPS; ++m) {
+            float v = part[s][m];
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+            if (lane == 0) red[wave][s][m] = v;
+        }
     __syncthreads();
-    if (threadIdx.x <= CV_KMAX) {
-        float t = 0.f;
-        for (int wv = 0; wv < CV_THREADS / 64; ++wv) t += red[wv][threadIdx.x];
-        if (threadIdx.x < CV_KMAX) {
-            if ((int)threadIdx.x < K && t != 0.f) atomicAdd(&a.dw[e * K + threadIdx.x], t);
-        } else if (a.dbias && t != 0.f) {
-            atomicAdd(&a.dbias[e], t);
+    const int t = threadIdx.x;
+    if (t < NSETS * (CV_KMAX + 1)) {
+        const int s = t / (CV_KMAX + 1), k = t % (CV_KMAX + 1);
+        const cad_conv1d_bwd_args& a = sets.s[s];
+        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
+        if (k < CV_KMAX) {
+            if (k < a.K) {
+                const int m = tap_index(k, a.K, rev);
+                float tot = 0.f;
+                for (int wv = 0; wv < CV_WAVES; ++wv) tot += red[wv][s][m];
+                if (tot != 0.f) atomicAdd(&a.dw[e * a.K + k], tot);
+            }
+        } else if (a.dbias) {
+            float tot = 0.f;
+            for (int wv = 0; wv < CV_WAVES; ++wv) tot += red[wv][s][CV_TAPS];
+            if (tot != 0.f) atomicAdd(&a.dbias[e], tot);
         }
     }
 }
 
 }  // namespace
 
-extern "C" int cad_conv1d_fwd(const cad_conv1d_args* a, void* stream) {
-    CAD_CHECK_ARG(a && a->x && a->w && a->out);
-    CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->K >= 1 && a->K <= CV_KMAX);
-    CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB);
-    CAD_CHECK_ARG((int64_t)a->E * a->SB < (1LL << 31));
+extern "C" int cad_conv1d_fwd_multi(const cad_conv1d_args* sets, int nsets, void* stream) {
+    CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= CV_MAXSETS);
+    ConvFwdSets ks;
+    for (int i = 0; i < nsets; ++i) {
+        const cad_conv1d_args* a = &sets[i];
+        CAD_CHECK_ARG(a->x && a->w && a->out);
+        CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->K >= 1 && a->K <= CV_KMAX);
+        CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB);
+        CAD_CHECK_ARG((int64_t)a->E * a->SB < (1LL << 31));
+        CAD_CHECK_ARG(a->x == sets[0].x && a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L &&
+                      a->dtype == sets[0].dtype);
+        ks.s[i] = *a;
+    }
+    for (int i = nsets; i < CV_MAXSETS; ++i) ks.s[i] = sets[0];
+    const cad_conv1d_args* a = &sets[0];
     CadProfScope prof(2, stream);
-    const int64_t per_block = (int64_t)CV_THREADS * CV_VEC;
+    const int64_t per_block = (int64_t)CV_WAVES * CV_WAVE_POS;
     dim3 grid((unsigned)((int64_t)a->E * a->SB), (unsigned)((a->L + per_block - 1) / per_block)), block(CV_THREADS);
     if (grid.y > 65535u) return CAD_ERR_UNSUPPORTED;
-    if (a->dtype == CAD_F32)
-        CAD_LAUNCH((conv1d_fwd_kernel<float>), grid, block, 0, stream, *a);
-    else if (a->dtype == CAD_BF16)
-        CAD_LAUNCH((conv1d_fwd_kernel<bf16_t>), grid, block, 0, stream, *a);
-    else
+    if (a->dtype == CAD_F32) {
+        if (nsets == 1)
+            CAD_LAUNCH((conv1d_fwd_kernel<float, 1>), grid, block, 0, stream, ks);
+        else
+            CAD_LAUNCH((conv1d_fwd_kernel<float, 2>), grid, block, 0, stream, ks);
+    } else if (a->dtype == CAD_BF16) {
+        if (nsets == 1)
+            CAD_LAUNCH((conv1d_fwd_kernel<bf16_t, 1>), grid, block, 0, stream, ks);
+        else
+            CAD_LAUNCH((conv1d_fwd_kernel<bf16_t, 2>), grid, block, 0, stream, ks);
+    } else {
         return CAD_ERR_UNSUPPORTED;
+    }
     return cad_after_launch();
 }
 
-extern "C" int cad_conv1d_bwd(const cad_conv1d_bwd_args* a, void* stream) {
-    CAD_CHECK_ARG(a && a->x && a->w && a->dout && a->dx && a->dw);
-    CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->K >= 1 && a->K <= CV_KMAX);
-    CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB);
+extern "C" int cad_conv1d_fwd(const cad_conv1d_args* a, void* stream) { return cad_conv1d_fwd_multi(a, 1, stream); }
+
+extern "C" int cad_conv1d_bwd_multi(const cad_conv1d_bwd_args* sets, int nsets, void* stream) {
+    CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= CV_MAXSETS);
+    ConvBwdSets ks;
+    for (int i = 0; i < nsets; ++i) {
+        const cad_conv1d_bwd_args* a = &sets[i];
+        CAD_CHECK_ARG(a->x && a->w && a->dout && a->dx && a->dw);
+        CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->K >= 1 && a->K <= CV_KMAX);
+        CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB);
+        CAD_CHECK_ARG(a->x == sets[0].x && a->dx == sets[0].dx && a->accumulate == sets[0].accumulate &&
+                      a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L && a->dtype == sets[0].dtype);
+        ks.s[i] = *a;
+    }
+    for (int i = nsets; i < CV_MAXSETS; ++i) ks.s[i] = sets[0];
+    const cad_conv1d_bwd_args* a = &sets[0];
     CadProfScope prof(3, stream);
-    const int64_t per_block = (int64_t)CV_THREADS * CV_VEC;
+    const int64_t per_block = (int64_t)CV_WAVES * CV_WAVE_POS * CV_TILES_BWD;
     dim3 grid((unsigned)((int64_t)a->E * a->SB), (unsigned)((a->L + per_block - 1) / per_block)), block(CV_THREADS);
     if (grid.y > 65535u) return CAD_ERR_UNSUPPORTED;
-    if (a->dtype == CAD_F32)
-        CAD_LAUNCH((conv1d_bwd_kernel<float>), grid, block, 0, stream, *a);
-    else if (a->dtype == CAD_BF16)
-        CAD_LAUNCH((conv1d_bwd_kernel<bf16_t>), grid, block, 0, stream, *a);
-    else
+    if (a->dtype == CAD_F32) {
+        if (nsets == 1)
+            CAD_LAUNCH((conv1d_bwd_kernel<float, 1>), grid, block, 0, stream, ks);
+        else
+            CAD_LAUNCH((conv1d_bwd_kernel<float, 2>), grid, block, 0, stream, ks);
+    } else if (a->dtype == CAD_BF16) {
+        if (nsets == 1)
+            CAD_LAUNCH((conv1d_bwd_kernel<bf16_t, 1>), grid, block, 0, stream, ks);
+        else
+            CAD_LAUNCH((conv1d_bwd_kernel<bf16_t, 2>), grid, block, 0, stream, ks);
+    } else {
         return CAD_ERR_UNSUPPORTED;
+    }
     return cad_after_launch();
 }
+
+extern "C" int cad_conv1d_bwd(const cad_conv1d_bwd_args* a, void* stream) { return cad_conv1d_bwd_multi(a, 1, stream); }

@@ -8,7 +8,7 @@ readable specification).  Scheduling the backward by hand removes what generic a
   * the scan backward writes dz of parameter set f straight into the dxz buffer and set r's dz is added in place;
   * weight gradients (reductions over all T tokens with tiny outputs) run as strided-batch GEMMs over 64 K-chunks plus an
     fp32 sum, 3-5x faster than the un-split library GEMM;
-  * conv backward of set r accumulates onto set f's dx in-kernel; dB/dC partial sums are reduced straight into the rows of
+  * the conv forward / backward of both parameter sets run as one launch each (x read once, dx = dx_f + dx_r written once); dB/dC partial sums are reduced straight into the rows of
     the x_proj gradient operand; du is folded into the x_proj backward GEMM (addmm).
 All kernels are the C-ABI entry points of include/caduceus_hip.h; GEMMs are hipBLASLt through torch.
 """
@@ -21,25 +21,37 @@ import torch
 from . import _lib as L
 
 
-def _conv_fwd(x, wf, bf, split, rl, rh):
+def _conv_fwd2(x, params, split, dirs):
+    """Both parameter sets' causal conv + SiLU of the same x in one launch (x is read once).  params: [(wf, bf)] * 2."""
     E, SB, Lq = x.shape
-    out = torch.empty_like(x)
-    stream = L.stream_and_check(x, wf, bf, out)
-    a = L.Conv1dArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(out), SB, Lq, split, E, wf.shape[1], rl, rh,
-                     L.dtype_code(x.dtype))
-    L.check(L.get_lib().cad_conv1d_fwd(C.byref(a), stream), "cad_conv1d_fwd")
-    return out
+    n = len(params)
+    args = (L.Conv1dArgs * n)()
+    outs = []
+    for i, (wf, bf) in enumerate(params):
+        out = torch.empty_like(x)
+        stream = L.stream_and_check(x, wf, bf, out)
+        args[i] = L.Conv1dArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(out), SB, Lq, split, E, wf.shape[1], dirs[i][0],
+                               dirs[i][1], L.dtype_code(x.dtype))
+        outs.append(out)
+    L.check(L.get_lib().cad_conv1d_fwd_multi(args, n, stream), "cad_conv1d_fwd_multi")
+    return outs
 
 
-def _conv_bwd(x, wf, bf, dout, dx, split, rl, rh, accumulate):
+def _conv_bwd2(x, params, douts, dx, split, dirs):
+    """dx = sum over both parameter sets of their input gradients (written once), dw / dbias per set."""
     E, SB, Lq = x.shape
-    dw = torch.zeros_like(wf)
-    db = None if bf is None else torch.zeros_like(bf)
-    stream = L.stream_and_check(x, wf, bf, dout, dx, dw, db)
-    a = L.Conv1dBwdArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(dout), L.ptr(dx), L.ptr(dw), L.ptr(db), SB, Lq, split, E,
-                        wf.shape[1], rl, rh, L.dtype_code(x.dtype), int(accumulate))
-    L.check(L.get_lib().cad_conv1d_bwd(C.byref(a), stream), "cad_conv1d_bwd")
-    return dw, db
+    n = len(params)
+    args = (L.Conv1dBwdArgs * n)()
+    res = []
+    for i, (wf, bf) in enumerate(params):
+        dw = torch.zeros_like(wf)
+        db = None if bf is None else torch.zeros_like(bf)
+        stream = L.stream_and_check(x, wf, bf, douts[i], dx, dw, db)
+        args[i] = L.Conv1dBwdArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(douts[i]), L.ptr(dx), L.ptr(dw), L.ptr(db), SB, Lq,
+                                  split, E, wf.shape[1], dirs[i][0], dirs[i][1], L.dtype_code(x.dtype), 0)
+        res.append((dw, db))
+    L.check(L.get_lib().cad_conv1d_bwd_multi(args, n, stream), "cad_conv1d_bwd_multi")
+    return res
 
 
 def _kchunks(T: int) -> int:
@@ -90,12 +102,17 @@ class BiMambaMixerFn(torch.autograd.Function):
         x, z = xz[:E], xz[E:]
         sets, saved = [], []
         dirs = ((0, 1), (1, 0))
+        cparams = []
+        for i in range(2):
+            conv_w, conv_b = ps[7 * i], ps[7 * i + 1]
+            cparams.append((conv_w.float().reshape(E, -1).contiguous(),
+                            None if conv_b is None else conv_b.float().contiguous()))
+        xcs = _conv_fwd2(x, cparams, split, dirs)
         for i in range(2):
             conv_w, conv_b, W_x, W_dt, dt_bias, A_log, Dp = ps[7 * i:7 * i + 7]
             N, R = A_log.shape[1], W_dt.shape[1]
-            wf = conv_w.float().reshape(E, -1).contiguous()
-            bf = None if conv_b is None else conv_b.float().contiguous()
-            xc = _conv_fwd(x, wf, bf, split, *dirs[i])
+            wf, bf = cparams[i]
+            xc = xcs[i]
             w_x, w_dt = W_x.to(act), W_dt.to(act)
             dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
             delta = torch.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
@@ -165,7 +182,7 @@ class BiMambaMixerFn(torch.autograd.Function):
                                     dirs[i][0], dirs[i][1], L.dtype_code(act), npart)
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
         L.check(lib.cad_scan_bwd_multi(args, 2, stream), "cad_scan_bwd_multi")
-        grads = []
+        grads, dxcs, part = [], [], []
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
             du, ddelta, dA, dD, dbias, dBC, npart = work[i]
@@ -181,12 +198,15 @@ class BiMambaMixerFn(torch.autograd.Function):
             torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
             dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
-            dxc = torch.addmm(du.view(E, T), w_x.t(), ddbc.view(R + 2 * N, T)).view(E, SB, Lq)
-            dwc, dbc_conv = _conv_bwd(x, wf, bf, dxc, dxz[:E], split, dirs[i][0], dirs[i][1], accumulate=(i == 1))
+            dxcs.append(torch.addmm(du.view(E, T), w_x.t(), ddbc.view(R + 2 * N, T)).view(E, SB, Lq))
+            part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
+        conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs)
+        for i in range(2):
             meta = pmeta[i]
-            dA_log = (dA * A).to(meta[5][0])  # A = -exp(A_log)  =>  dA/dA_log = A
+            (dwc, dbc_conv), (dW_x, dW_dt, dbias, dA_log, dD) = conv_g[i], part[i]
             grads += [dwc.reshape(meta[0][1]).to(meta[0][0]), None if dbc_conv is None else dbc_conv.to(meta[1][0]),
-                      dW_x.to(meta[2][0]), dW_dt.to(meta[3][0]), dbias.to(meta[4][0]), dA_log, dD.to(meta[6][0])]
+                      dW_x.to(meta[2][0]), dW_dt.to(meta[3][0]), dbias.to(meta[4][0]), dA_log.to(meta[5][0]),
+                      dD.to(meta[6][0])]
         dxz[E:].add_(dz_r)  # the two parameter sets share the gate z
         dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
         dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)

@@ -141,6 +141,9 @@ typedef struct {
     int dtype;
 } cad_conv1d_args;
 int cad_conv1d_fwd(const cad_conv1d_args* a, void* stream);
+/* nsets (1 or 2) parameter sets reading the SAME x (mamba_fwd / mamba_rev of a BiMamba layer see one in_proj output in
+ * opposite directions, modeling_caduceus.py:128-130): x is read once. */
+int cad_conv1d_fwd_multi(const cad_conv1d_args* sets, int nsets, void* stream);
 /* dx is WRITTEN (dtype), or ADDED to when accumulate != 0 (the second parameter set of a BiMamba layer adds its input
  * gradient onto the first one's); dw (E,K) and dbias (E) fp32 are ACCUMULATED (caller zeroes). */
 typedef struct {
@@ -158,6 +161,8 @@ typedef struct {
     int accumulate;
 } cad_conv1d_bwd_args;
 int cad_conv1d_bwd(const cad_conv1d_bwd_args* a, void* stream);
+/* nsets (1 or 2) parameter sets with the same x, dx and accumulate flag: dx = (accumulate ? dx : 0) + sum over the sets. */
+int cad_conv1d_bwd_multi(const cad_conv1d_bwd_args* sets, int nsets, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Selective SSM scan, one direction per row.   Replaces selective_scan_cuda.fwd / .bwd reached through

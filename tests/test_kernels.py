@@ -273,3 +273,33 @@ def test_scan_tm_forward_two_sets_mirror(backend):
     r = ops.scan_tm_forward([(u, delta, A, BC, D, bias), (f(u), f(delta), A, f(BC), D, bias)], None, SB, [(0, 0), (1, 1)])
     assert torch.equal(r[0][0], f(r[1][0]))
     assert torch.equal(r[0][1], r[1][1])  # saved states are indexed by logical position
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(5, 2, 75, 4), (3, 3, 2100, 3), (6, 2, 4096, 4)])
+def test_causal_conv1d_two_sets(backend, case, dtype):
+    """cad_conv1d_fwd_multi / cad_conv1d_bwd_multi (two parameter sets on one x, opposite directions, dx summed) are
+    identical to two single-set launches."""
+    from caduceus_amd import mixer
+    name, dev = backend
+    E, SB, L, K = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(E, SB, L, generator=g).to(dev).to(dtype)
+    params = [(torch.randn(E, K, generator=g).to(dev), torch.randn(E, generator=g).to(dev)) for _ in range(2)]
+    douts = [torch.randn(E, SB, L, generator=g).to(dev).to(dtype) for _ in range(2)]
+    dirs, split = ((0, 1), (1, 0)), 1
+    outs = mixer._conv_fwd2(x, params, split, dirs)
+    dx = torch.empty_like(x)
+    grads = mixer._conv_bwd2(x, params, douts, dx, split, dirs)
+    dx_ref = torch.zeros(E, SB, L, device=dev)
+    for i in range(2):
+        xi = x.clone().requires_grad_(True)
+        wi, bi = (p.clone().requires_grad_(True) for p in params[i])
+        oi = ops.causal_conv1d(xi, wi.view(E, 1, K), bi, split, *dirs[i])
+        assert torch.equal(oi, outs[i])
+        oi.backward(douts[i])
+        dx_ref += xi.grad.float()
+        tol = FP32 if dtype == torch.float32 else BF16
+        torch.testing.assert_close(grads[i][0], wi.grad.view(E, K), rtol=1e-4, atol=1e-4 * max(1.0, float(wi.grad.abs().max())))
+        torch.testing.assert_close(grads[i][1], bi.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(bi.grad.abs().max())))
+    torch.testing.assert_close(dx.float(), dx_ref, **(FP32 if dtype == torch.float32 else BF16))
