@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="sequences per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-sample", type=int, default=4096, help="tokens of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--model", default="ps", choices=["ps", "ph"],
+                    help="ps: RCPS (configs[2..4], the headline); ph: no RCPS wrapper, RC augmentation is a data-side flip "
+                         "(configs[1], run with --seqlen 1024 --batch 128)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -108,7 +111,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
 
     torch.manual_seed(2222)  # configs/experiment/hg38/hg38.yaml:54; identical initial weights on every rank
-    model = CaduceusForMaskedLM(make_config(args.d_model, args.n_layer)).to(dev).train()
+    model = CaduceusForMaskedLM(make_config(args.d_model, args.n_layer, rcps=args.model == "ps")).to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
     reducer = BucketedGradReducer(model.parameters())
     decay, no_decay = [], []
@@ -159,8 +162,9 @@ def main():
         tokens = args.batch * args.seqlen * world * args.steps
         E, N = 2 * args.d_model, SSM_CFG["d_state"]
         s = 2 if args.dtype == "bf16" else 4
-        # one launch = both strands x both parameter sets (mamba_fwd, mamba_rev) of a layer = 4 Mamba invocations/token
-        inv_tokens = 4 * args.batch * args.seqlen
+        # one launch = (both strands x) both parameter sets (mamba_fwd, mamba_rev) of a layer = 4 (PS) / 2 (Ph) Mamba
+        # invocations per token
+        inv_tokens = (4 if args.model == "ps" else 2) * args.batch * args.seqlen
         alg = {"scan_fwd": (4 * E + 2 * N) * s * inv_tokens, "scan_bwd": (7 * E + 4 * N) * s * inv_tokens}
         kinds = {}
         for k in ("scan_fwd", "scan_bwd"):
@@ -170,15 +174,52 @@ def main():
                             "algorithmic_bytes_per_launch": alg[k], "total_ms": ms}
         dom = max(kinds, key=lambda k: kinds[k]["total_ms"]) if kinds else None
         roofline = None
+        # HBM traffic of one scan launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with
+        # rocprofv3 --pmc at exactly this launch shape); null for any other shape
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_scan_pmc.json")))
+            sh = pmc["shape"]
+            if dom and (sh["E"], sh["L"], sh["N"], sh["dtype"]) == (E, args.seqlen, N, args.dtype) and \
+                    sh["rows"] == (2 if args.model == "ps" else 1) * args.batch:
+                traffic = pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         if dom:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": kinds[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": kinds[dom]["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": kinds[dom]["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_note": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_scan_pmc.json)",
                         "avg_launch_ms": kinds[dom]["avg_ms"], "launches": kinds[dom]["launches"],
                         "algorithmic_bytes_per_launch": kinds[dom]["algorithmic_bytes_per_launch"],
                         "all": {k: {"avg_ms": v["avg_ms"], "achieved_GBps": v["achieved_GBps"],
                                     "share_of_step": v["total_ms"] / (elapsed * 1e3)} for k, v in kinds.items()},
                         "other_kernels_ms_per_step": {k: prof[k][0] / args.steps for k in prof
                                                       if k not in kinds and prof[k][1]}}
+        # MFMA evidence for the dense projections (north_star): the in_proj GEMM of this workload, timed stand-alone
+        proj = None
+        try:
+            Tt = (2 if args.model == "ps" else 1) * args.batch * args.seqlen
+            xx = torch.randn(Tt, args.d_model, device=dev, dtype=amp)
+            ww = torch.randn(2 * E, args.d_model, device=dev, dtype=amp)
+            for _ in range(3):
+                torch.mm(ww, xx.t())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                torch.mm(ww, xx.t())
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            fl = 2.0 * Tt * args.d_model * 2 * E
+            by = (Tt * args.d_model + 2 * E * args.d_model + Tt * 2 * E) * (2 if args.dtype == "bf16" else 4)
+            proj = {"kernel": "in_proj GEMM (hipBLASLt, MFMA)", "ms": ms, "TFLOPs": fl / ms / 1e9,
+                    "mfma_peak_TFLOPs": 2500.0 if args.dtype == "bf16" else 157.3, "GBps": by / ms / 1e6,
+                    "note": "K = d_model = 256: the GEMM is HBM-bound (arithmetic intensity ~200 flop/B), not MFMA-bound"}
+            del xx, ww
+        except Exception as ex:  # evidence only
+            proj = {"error": repr(ex)}
+        if roofline is not None:
+            roofline["projections"] = proj
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             try:
@@ -191,8 +232,9 @@ def main():
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"Caduceus-PS d_model={args.d_model} n_layer={args.n_layer} seqlen={args.seqlen} "
-                                   f"rcps=true MLM fwd+bwd+allreduce+AdamW, {args.batch} seq/GPU",
+            "config": {"workload": f"Caduceus-{args.model.upper() if args.model == 'ps' else 'Ph'} d_model={args.d_model} "
+                                   f"n_layer={args.n_layer} seqlen={args.seqlen} rcps={'true' if args.model == 'ps' else 'false'} "
+                                   f"MLM fwd+bwd+allreduce+AdamW, {args.batch} seq/GPU",
                        "global_batch": args.batch * world, "seq_len": args.seqlen, "parallelism": f"dp{world}",
                        "params": n_params, "final_loss": float(loss)},
             "roofline": roofline, "cpu_baseline": cpu,
