@@ -121,9 +121,10 @@ class BiMambaMixerFn(torch.autograd.Function):
         # both parameter sets in one scan launch
         args = (L.ScanArgs * 2)()
         outs, states = [], []
+        ycat = torch.empty((2 * E, SB, Lq), dtype=act, device=x2d.device)  # [y_f ; y_r]: one out_proj GEMM with K = 2E
         for i, (xc, delta, A, dbc, Df, bfz, *_rest) in enumerate(sets):
             N, R = A.shape[1], dbc.shape[0] - 2 * A.shape[1]
-            out = torch.empty_like(xc)
+            out = ycat[i * E:(i + 1) * E]
             state = torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=xc.device)
             Bm, Cm = dbc[R:R + N], dbc[R + N:]
             stream = L.stream_and_check(xc, delta, A, Bm, Cm, Df, z, bfz, out, state)
@@ -134,9 +135,8 @@ class BiMambaMixerFn(torch.autograd.Function):
             states.append(state)
         L.check(lib.cad_scan_fwd_multi(args, 2, stream), "cad_scan_fwd_multi")
         y_f, y_r = outs
-        out2d = torch.mm(y_f.view(E, T).t(), w_out.t())
-        out2d = torch.addmm(out2d, y_r.view(E, T).t(), w_out.t())
-        keep = [x2d, xz, w_in, w_out, y_f, y_r]
+        out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
+        keep = [x2d, xz, w_in, w_out, ycat]
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt = sets[i]
             keep += [xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, states[i], ps[7 * i + 5]]
@@ -148,7 +148,7 @@ class BiMambaMixerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout2d):
         lib = L.get_lib()
-        x2d, xz, w_in, w_out, y_f, y_r, *rest = ctx.saved_tensors
+        x2d, xz, w_in, w_out, ycat, *rest = ctx.saved_tensors
         SB, Lq, split, pmeta, win_dt, wout_dt = ctx.meta
         act = x2d.dtype
         T, Dm = x2d.shape
@@ -158,7 +158,9 @@ class BiMambaMixerFn(torch.autograd.Function):
         dout2d = dout2d.contiguous()
         # tied out_proj: the gradient w.r.t. y_f and y_r is the same tensor, produced channel-major
         dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)
-        dW_out = (_wgrad_cm_tm(y_f.view(E, T), dout2d) + _wgrad_cm_tm(y_r.view(E, T), dout2d)).t()
+        y_f, y_r = ycat[:E], ycat[E:]
+        dW_cat = _wgrad_cm_tm(ycat.view(2 * E, T), dout2d)  # (2E, D): both halves multiply the same tied weight
+        dW_out = (dW_cat[:E] + dW_cat[E:]).t()
         dxz = torch.empty_like(xz)       # [dx ; dz_f + dz_r]
         dz_r = torch.empty_like(z)
         sets = [rest[12 * i:12 * i + 12] for i in range(2)]
@@ -198,7 +200,8 @@ class BiMambaMixerFn(torch.autograd.Function):
             torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
             dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
-            dxcs.append(torch.addmm(du.view(E, T), w_x.t(), ddbc.view(R + 2 * N, T)).view(E, SB, Lq))
+            du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))  # in place: no copy of the 268 MB addend
+            dxcs.append(du)
             part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
         conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs)
         for i in range(2):
