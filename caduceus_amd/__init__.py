@@ -9,8 +9,9 @@ from .modeling_caduceus import (BiMambaWrapper, Caduceus, CaduceusForMaskedLM, C
                                 CaduceusMixerModel, create_block)
 from .modeling_rcps import RCPSAddNormWrapper, RCPSEmbedding, RCPSLMHead, RCPSMambaBlock, RCPSWrapper
 from .tokenization_caduceus import CaduceusTokenizer
+from .downstream import DNAEmbeddingModelCaduceus, SequenceDecoder
 
-__all__ = ["CaduceusConfig", "Caduceus", "CaduceusForMaskedLM", "CaduceusForSequenceClassification",
+__all__ = ["DNAEmbeddingModelCaduceus", "SequenceDecoder", "CaduceusConfig", "Caduceus", "CaduceusForMaskedLM", "CaduceusForSequenceClassification",
            "CaduceusTokenizer", "CaduceusMixerModel", "BiMambaWrapper", "create_block", "RCPSEmbedding", "RCPSWrapper",
            "RCPSAddNormWrapper", "RCPSMambaBlock", "RCPSLMHead", "register_auto_classes"]
 
