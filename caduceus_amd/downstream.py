@@ -68,11 +68,12 @@ class SequenceDecoder(nn.Module):
             return x_seq[..., -l_output:, :]
         if mode == "first":
             return x_seq[..., :l_output, :]
-        if mode == "pool":  # running mean: output j = mean of positions [0, L - l_output + j]; length axis = -2
-            L = x_seq.size(-2)
-            prefix = torch.cumsum(x_seq, dim=-2)[..., L - l_output:, :]
+        if mode == "pool":  # running mean: output j = mean of positions [0, L - l_output + j]
+            ax = 1 if x_seq.dim() >= 3 else 0  # (B, L, D[, 2]) batches, or one (L, D) sample under use_lengths
+            L = x_seq.size(ax)
+            prefix = torch.cumsum(x_seq, dim=ax).narrow(ax, L - l_output, l_output)
             count = torch.arange(L - l_output + 1, L + 1, dtype=x_seq.dtype, device=x_seq.device)
-            return prefix / count.unsqueeze(-1)
+            return prefix / count.view(*([1] * ax), -1, *([1] * (x_seq.dim() - ax - 1)))
         if mode == "sum":
             return torch.cumsum(x_seq, dim=-2)[..., -l_output:, :]
         if mode == "ragged":
