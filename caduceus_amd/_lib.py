@@ -79,6 +79,12 @@ class ScanTmArgs(C.Structure):
                 ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
 
 
+class MlmArgs(C.Structure):
+    _fields_ = [("bases", _p), ("rc_flags", _p), ("lengths", _p), ("input_ids", _p), ("labels", _p), ("B", _i64),
+                ("L", _i64), ("ld_bases", _i64), ("seed", C.c_uint64), ("offset", C.c_uint64), ("thr_mask", C.c_uint32),
+                ("pad_id", _i), ("mask_id", _i), ("unk_id", _i), ("n_id", _i), ("vocab", _i), ("base_ids", _i * 4)]
+
+
 class LmHeadArgs(C.Structure):
     _fields_ = [("hidden", _p), ("weight", _p), ("comp", _p), ("labels", _p), ("logits", _p), ("loss_sum", _p),
                 ("count", _p), ("rows", _i64), ("D", _i), ("V", _i), ("n_strands", _i), ("ignore_index", _i64),
@@ -112,6 +118,16 @@ SYMBOLS = {
     "cad_scan_tm_state_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_scan_tm_scratch_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
+    "cad_tokenize_mlm": (_i, [C.POINTER(MlmArgs), _p]),
+    "cad_mlm_threshold": (C.c_uint32, [C.c_double]),
+    "cad_hg38_interval": (_i, [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "cad_fasta_open": (_i, [C.c_char_p, C.POINTER(_p)]),
+    "cad_fasta_close": (_i, [_p]),
+    "cad_fasta_num_seqs": (_i64, [_p]),
+    "cad_fasta_seq_name": (C.c_char_p, [_p, _i64]),
+    "cad_fasta_seq_len": (_i64, [_p, _i64]),
+    "cad_fasta_find": (_i64, [_p, C.c_char_p]),
+    "cad_fasta_fetch": (_i, [_p, _i64, _i64, _i64, _p]),
     "cad_prof_enable": (_i, [_i]),
     "cad_prof_reset": (_i, []),
     "cad_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),

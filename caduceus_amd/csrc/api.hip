@@ -47,7 +47,7 @@ CadProfScope::CadProfScope(int k, void* s) : kind(k), stream(s), slot(-1) {
     Rec r;
     r.kind = k;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    hipEventRecord(r.a, (hipStream_t)s);
+    (void)hipEventRecord(r.a, (hipStream_t)s);
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
 #else
@@ -58,7 +58,7 @@ CadProfScope::CadProfScope(int k, void* s) : kind(k), stream(s), slot(-1) {
 CadProfScope::~CadProfScope() {
 #ifndef CAD_EMU
     std::lock_guard<std::mutex> lk(g_mu);
-    if (slot >= 0 && slot < (int)g_recs.size()) hipEventRecord(g_recs[slot].b, (hipStream_t)stream);
+    if (slot >= 0 && slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, (hipStream_t)stream);
 #endif
 }
 
@@ -72,8 +72,8 @@ extern "C" int cad_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
 #ifndef CAD_EMU
     for (auto& r : g_recs) {
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_recs.clear();
 #else

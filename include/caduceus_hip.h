@@ -299,6 +299,51 @@ typedef struct {
 int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * hg38 data path -- the step in front of the model.
+ *
+ * cad_tokenize_mlm: ASCII bases -> (input_ids, labels) on the GPU in one pass.  Replaces, per batch, the per-sample
+ * Python of HG38Dataset.__getitem__ (src/dataloaders/datasets/hg38_dataset.py:160-227): the CaduceusTokenizer character
+ * path (upper-casing, unknown characters -> [UNK]; caduceus/tokenization_caduceus.py:104-110), string_reverse_complement
+ * (src/dataloaders/utils/rc.py:17-26) for rows whose rc flag is set, replace_value(N -> [PAD]) (:212), left padding to L,
+ * and mlm_getitem (src/dataloaders/utils/mlm.py:4-32): Bernoulli(p) targets, of which 80 % become [MASK], 10 % a random
+ * id in [0, vocab), 10 % stay; labels = [PAD] everywhere else.  labels == NULL: tokenisation only.
+ * Random numbers are Philox4x32-10 with key = seed and counter = (position, row, offset): reproducible, independent of the
+ * launch geometry, restated bit for bit by oracle/data_oracle.py (they are NOT torch's CPU generator stream, so batches
+ * are equal to the reference's in distribution, not sample by sample).
+ *   bases: (B, ld_bases) bytes, row b holds lengths[b] bases (lengths NULL: L each); rc_flags: (B) bytes or NULL.
+ *   thr_mask = cad_mlm_threshold(mlm_probability); base_ids = ids of A, C, G, T. */
+typedef struct {
+    const uint8_t* bases;
+    const uint8_t* rc_flags;
+    const int64_t* lengths;
+    int64_t* input_ids;
+    int64_t* labels;
+    int64_t B, L, ld_bases;
+    uint64_t seed, offset;
+    uint32_t thr_mask;
+    int pad_id, mask_id, unk_id, n_id, vocab;
+    int base_ids[4];
+} cad_mlm_args;
+int cad_tokenize_mlm(const cad_mlm_args* a, void* stream);
+uint32_t cad_mlm_threshold(double probability);
+
+/* Host side.  cad_hg38_interval = the interval arithmetic of FastaInterval.__call__ (hg38_dataset.py:41-89): the
+ * i_shift-th max_length window of [start, start + 2^20), shifted back inside [0, chrom_len).  Returns
+ * CAD_ERR_UNSUPPORTED where the reference raises ValueError (max_length > 2^20).
+ * cad_fasta_*: memory-mapped FASTA (replaces pyfaidx.Fasta as used at hg38_dataset.py:30-39,84): index built on open,
+ * cad_fasta_fetch copies bases [start, end) of sequence `seq` without line breaks into `out` (caller-owned, end - start
+ * bytes, e.g. a pinned staging buffer). */
+int cad_hg38_interval(int64_t start, int64_t end, int64_t max_length, int64_t i_shift, int64_t chrom_len,
+                      int64_t* out_start, int64_t* out_end);
+int cad_fasta_open(const char* path, void** handle);
+int cad_fasta_close(void* handle);
+int64_t cad_fasta_num_seqs(void* handle);
+const char* cad_fasta_seq_name(void* handle, int64_t i);
+int64_t cad_fasta_seq_len(void* handle, int64_t i);
+int64_t cad_fasta_find(void* handle, const char* name);
+int cad_fasta_fetch(void* handle, int64_t seq, int64_t start, int64_t end, uint8_t* out);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Opt-in kernel timer (HIP events on the launch stream) used by bench.py for the roofline line.
  * kind: 0 scan_fwd, 1 scan_bwd, 2 conv_fwd, 3 conv_bwd, 4 add_norm_fwd, 5 add_norm_bwd, 6 embed, 7 lm_head. */
 #define CAD_PROF_KINDS 8
