@@ -5,8 +5,8 @@
 // sides come from the neighbouring lanes through DPP wave shifts, so every element of x / dout is loaded exactly once.
 // Lanes 0 and 63 of a wave are halo lanes (they load and pre-compute but do not store), i.e. a wave produces 62 * 8 =
 // 496 positions.  Working in physical order makes the direction a choice of taps instead of an index map: a row that
-// runs left-to-right uses the taps on its left, a right-to-left row the mirrored taps on its right, expressed as one
-// 7-tap window W7 around the position with the unused taps set to zero.
+// runs left-to-right uses the taps on its left, a right-to-left row the mirrored taps on its right (template parameter,
+// selected by a wave-uniform branch).
 // Up to two parameter sets that read the SAME x (mamba_fwd / mamba_rev of a BiMamba layer, which see the same in_proj
 // output in opposite directions) run in one launch: x is read once, and in the backward dx = dx_0 + dx_1 is written once.
 #include "cad_common.h"
@@ -77,24 +77,26 @@ __device__ __forceinline__ void halo_window(const float* own, float* e) {
     for (int j = 0; j < CV_VEC; ++j) e[CV_HALO + j] = own[j];
 }
 
-// taps of the forward conv of a row with direction `rev` inside the 7-tap window (offset m - 3):
-// left-to-right: out[l] = b + sum_k w[k] x[l - (K-1) + k];  right-to-left: out[l] = b + sum_k w[k] x[l + (K-1) - k]
-__device__ __forceinline__ int tap_index(int k, int K, int rev) { return rev ? (CV_HALO + (K - 1) - k) : (CV_HALO - (K - 1) + k); }
-
-// b + sum over the window; the taps are accumulated in the order k = 0 .. K-1 of the row's own direction (ascending
-// window index for left-to-right taps, descending for right-to-left ones), so a right-to-left row is the exact mirror
-// -- same floating-point operation order -- of a left-to-right row on flipped data (zero taps add exact zeros).
-__device__ __forceinline__ float conv7(const float* W, const float* win, float b, int descending) {
+// Taps.  Weights are held as w4[0..3] aligned to K = 4 (w4[k] = w[k - (4 - K)], zero for the missing leading taps), so
+// that for any K <= 4 the conv of a left-to-right row is  b + sum_k w4[k] * win[k]  and of a right-to-left row
+// b + sum_k w4[k] * win[6 - k]  over the 7-value window win[0..6] = x[l-3 .. l+3].  The direction is a template
+// parameter (the row's direction is wave-uniform: one scalar branch selects the instantiation); taps are accumulated in
+// the same order k = 0..3 for both directions, so a right-to-left row is the exact mirror of a left-to-right row.
+template <int REV>
+__device__ __forceinline__ float conv4(const float* w4, const float* win, float b) {
     float acc = b;
-    if (descending) {
 #pragma unroll
-        for (int m = CV_TAPS - 1; m >= 0; --m) acc += W[m] * win[m];
-    } else {
-#pragma unroll
-        for (int m = 0; m < CV_TAPS; ++m) acc += W[m] * win[m];
-    }
-    return acc;
+    for (int k = 0; k < CV_KMAX; ++k) acc = __builtin_fmaf(w4[k], win[REV ? (CV_TAPS - 1 - k) : k], acc);  // explicit
+    return acc;  // fused multiply-adds: -ffp-contract may otherwise fuse the two direction instantiations differently
 }
+__device__ __forceinline__ void load_w4(const float* w, int e, int K, float* w4) {
+#pragma unroll
+    for (int k = 0; k < CV_KMAX; ++k) w4[k] = (k >= CV_KMAX - K) ? w[e * K + k - (CV_KMAX - K)] : 0.f;
+}
+template <int REV>
+struct DirTag {
+    static constexpr int value = REV;
+};
 
 template <typename T, int NSETS>
 __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets) {
@@ -107,23 +109,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets
     const int wave = cad_uniform(threadIdx.x >> 6);
     const T* x = (const T*)a0.x + rowid * L;
     bool vec_ok = (L % CV_VEC) == 0 && ((uintptr_t)a0.x % (sizeof(T) * CV_VEC)) == 0;
-    float W7[NSETS][CV_TAPS], bias[NSETS];
+    float W4[NSETS][CV_KMAX], bias[NSETS];
     int revs[NSETS];
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const cad_conv1d_args& a = sets.s[s];
         vec_ok = vec_ok && ((uintptr_t)a.out % (sizeof(T) * CV_VEC)) == 0;
-        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
-        revs[s] = rev;
-#pragma unroll
-        for (int m = 0; m < CV_TAPS; ++m) W7[s][m] = 0.f;
-        for (int k = 0; k < a.K; ++k) {
-            const int m = tap_index(k, a.K, rev);
-            const float wk = a.w[e * a.K + k];
-#pragma unroll
-            for (int mm = 0; mm < CV_TAPS; ++mm)
-                if (mm == m) W7[s][mm] = wk;
-        }
+        revs[s] = sb < a.split ? a.rev_lo : a.rev_hi;
+        load_w4(a.w, e, a.K, W4[s]);
         bias[s] = a.bias ? a.bias[e] : 0.f;
     }
     const int64_t tile = (int64_t)blockIdx.y * CV_WAVES + wave;
@@ -136,11 +129,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         float o[CV_VEC];
+        auto body = [&](auto dir) {
+            constexpr int REV = decltype(dir)::value;
 #pragma unroll
-        for (int j = 0; j < CV_VEC; ++j) {
-            const float acc = conv7(W7[s], xe + j, bias[s], revs[s]);
-            o[j] = acc * cad_sigmoid(acc);
-        }
+            for (int j = 0; j < CV_VEC; ++j) {
+                const float acc = conv4<REV>(W4[s], xe + j, bias[s]);
+                o[j] = acc * cad_sigmoid(acc);
+            }
+        };
+        if (revs[s]) body(DirTag<1>{}); else body(DirTag<0>{});
         if (useful) store8((T*)sets.s[s].out + rowid * L, l0, L, vec_ok, o);
     }
 }
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets
 // the opposite direction);  dw[k] = sum_l dpre[l] * x[l + offset_k];  dbias = sum_l dpre[l].
 template <typename T, int NSETS>
 __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets) {
-    __shared__ float red[CV_WAVES][NSETS][CV_TAPS + 1];
+    __shared__ float red[CV_WAVES][NSETS][CV_KMAX + 1];
     const cad_conv1d_bwd_args& a0 = sets.s[0];
     const int64_t rowid = blockIdx.x;
     const int e = (int)(rowid / a0.SB);
@@ -160,27 +157,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets
     const T* x = (const T*)a0.x + rowid * L;
     T* dx = (T*)a0.dx + rowid * L;
     bool vec_ok = (L % CV_VEC) == 0 && (((uintptr_t)a0.x | (uintptr_t)a0.dx) % (sizeof(T) * CV_VEC)) == 0;
-    float W7[NSETS][CV_TAPS], V7[NSETS][CV_TAPS], bias[NSETS], part[NSETS][CV_TAPS + 1];
+    float W4[NSETS][CV_KMAX], bias[NSETS], part[NSETS][CV_KMAX + 1];  // part: dw4[0..3], dbias
     int revs[NSETS];
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const cad_conv1d_bwd_args& a = sets.s[s];
         vec_ok = vec_ok && ((uintptr_t)a.dout % (sizeof(T) * CV_VEC)) == 0;
-        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
-        revs[s] = rev;
+        revs[s] = sb < a.split ? a.rev_lo : a.rev_hi;
+        load_w4(a.w, e, a.K, W4[s]);
 #pragma unroll
-        for (int m = 0; m < CV_TAPS; ++m) W7[s][m] = 0.f, V7[s][m] = 0.f;
-#pragma unroll
-        for (int m = 0; m <= CV_TAPS; ++m) part[s][m] = 0.f;
-        for (int k = 0; k < a.K; ++k) {
-            const int m = tap_index(k, a.K, rev), mt = tap_index(k, a.K, !rev);
-            const float wk = a.w[e * a.K + k];
-#pragma unroll
-            for (int mm = 0; mm < CV_TAPS; ++mm) {
-                if (mm == m) W7[s][mm] = wk;
-                if (mm == mt) V7[s][mm] = wk;
-            }
-        }
+        for (int m = 0; m <= CV_KMAX; ++m) part[s][m] = 0.f;
         bias[s] = a.bias ? a.bias[e] : 0.f;
     }
     const float useful = (lane >= 1 && lane <= 62) ? 1.f : 0.f;
@@ -201,21 +187,25 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets
         for (int s = 0; s < NSETS; ++s) {
             float g[CV_VEC], dpre[CV_VEC], dpe[CV_VEC + 2 * CV_HALO];
             load8((const T*)sets.s[s].dout + rowid * L, l0, L, vec_ok, g);
+            auto body = [&](auto dir) {
+                constexpr int REV = decltype(dir)::value;
 #pragma unroll
-            for (int j = 0; j < CV_VEC; ++j) {
-                const float acc = conv7(W7[s], xe + j, bias[s], revs[s]);
-                const float sg = cad_sigmoid(acc);
-                dpre[j] = g[j] * sg * (1.f + acc * (1.f - sg));  // dout is 0 outside [0, L) -> so is dpre
-            }
-            halo_window(dpre, dpe);
+                for (int j = 0; j < CV_VEC; ++j) {
+                    const float acc = conv4<REV>(W4[s], xe + j, bias[s]);
+                    const float sg = cad_sigmoid(acc);
+                    dpre[j] = g[j] * sg * (1.f + acc * (1.f - sg));  // dout is 0 outside [0, L) -> so is dpre
+                }
+                halo_window(dpre, dpe);
 #pragma unroll
-            for (int j = 0; j < CV_VEC; ++j) {
-                o[j] += conv7(V7[s], dpe + j, 0.f, !revs[s]);  // transposed conv = the taps of the opposite direction
-                const float dm = dpre[j] * useful;  // halo lanes belong to the neighbouring tile
+                for (int j = 0; j < CV_VEC; ++j) {
+                    o[j] += conv4<!REV>(W4[s], dpe + j, 0.f);  // transposed conv = the taps of the opposite direction
+                    const float dm = dpre[j] * useful;        // halo lanes belong to the neighbouring tile
 #pragma unroll
-                for (int m = 0; m < CV_TAPS; ++m) part[s][m] += dm * xe[j + m];
-                part[s][CV_TAPS] += dm;
-            }
+                    for (int k = 0; k < CV_KMAX; ++k) part[s][k] += dm * xe[j + (REV ? (CV_TAPS - 1 - k) : k)];
+                    part[s][CV_KMAX] += dm;
+                }
+            };
+            if (revs[s]) body(DirTag<1>{}); else body(DirTag<0>{});
         }
         if (useful != 0.f) store8(dx, l0, L, vec_ok, o);
     }
@@ -223,7 +213,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets
 #pragma unroll
     for (int s = 0; s < NSETS; ++s)
 #pragma unroll
-        for (int m = 0; m <= CV_TAPS; ++m) {
+        for (int m = 0; m <= CV_KMAX; ++m) {
             float v = part[s][m];
 #pragma unroll
             for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
@@ -234,17 +224,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets
     if (t < NSETS * (CV_KMAX + 1)) {
         const int s = t / (CV_KMAX + 1), k = t % (CV_KMAX + 1);
         const cad_conv1d_bwd_args& a = sets.s[s];
-        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
         if (k < CV_KMAX) {
-            if (k < a.K) {
-                const int m = tap_index(k, a.K, rev);
+            if (k < a.K) {  // w[k] lives in w4[k + 4 - K]
                 float tot = 0.f;
-                for (int wv = 0; wv < CV_WAVES; ++wv) tot += red[wv][s][m];
+                for (int wv = 0; wv < CV_WAVES; ++wv) tot += red[wv][s][k + CV_KMAX - a.K];
                 if (tot != 0.f) atomicAdd(&a.dw[e * a.K + k], tot);
             }
         } else if (a.dbias) {
             float tot = 0.f;
-            for (int wv = 0; wv < CV_WAVES; ++wv) tot += red[wv][s][CV_TAPS];
+            for (int wv = 0; wv < CV_WAVES; ++wv) tot += red[wv][s][CV_KMAX];
             if (tot != 0.f) atomicAdd(&a.dbias[e], tot);
         }
     }
