@@ -61,7 +61,8 @@ class Conv1dBwdArgs(C.Structure):
 class ScanArgs(C.Structure):
     _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
                 ("delta_bias", _p), ("out", _p), ("chunk_state", _p), ("SB", _i64), ("L", _i64), ("split", _i64),
-                ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
+                ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i), ("h0", _p), ("hT", _p),
+                ("sum_dt", _p)]
 
 
 class ScanBwdArgs(C.Structure):
@@ -69,7 +70,7 @@ class ScanBwdArgs(C.Structure):
                 ("delta_bias", _p), ("dout", _p), ("out", _p), ("chunk_state", _p), ("du", _p), ("ddelta", _p), ("dz", _p),
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
-                ("n_partials", _i)]
+                ("n_partials", _i), ("dhT", _p), ("dh0", _p)]
 
 
 class ScanTmArgs(C.Structure):

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         Areg = f2(a.A[e * N + n0], (n0 + 1 < N) ? a.A[e * N + n0 + 1] : 0.f);
     }
     f32x2 carryG = f2(0.f);  // lane np: G flowing out of the later chunk into this one, for pair np
+    if (a.dhT && lane < NP) {
+        const float* gp = a.dhT + ((int64_t)e * SB + sb) * N + 2 * lane;
+        carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
+    }
     f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
     float dDacc = 0.f, dbacc = 0.f;
     int tix = 0;
@@ -293,6 +297,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, go);
         }
+    }
+    if (a.dh0 && act && lane < NP) {  // gradient w.r.t. the state entering the row
+        float* gp = a.dh0 + ((int64_t)e * SB + sb) * N + 2 * lane;
+        gp[0] = carryG[0];
+        if (2 * lane + 1 < N) gp[1] = carryG[1];
     }
     // per-channel parameter gradients (E x N, E: a few device-scope atomics per wave, once per kernel)
     if (act && lane < NP) {

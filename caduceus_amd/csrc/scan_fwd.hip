@@ -50,6 +50,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     __syncthreads();
 
     f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
+    if (a.h0 && lane < NP) {
+        const float* hp = a.h0 + ((int64_t)e * SB + sb) * N + 2 * lane;
+        carry = f2(hp[0], (2 * lane + 1 < N) ? hp[1] : 0.f);
+    }
+    float sdt = 0.f;  // this lane's share of sum(dt) over the row
     // lane np holds (A[2np], A[2np+1]) * log2(e): read once, broadcast per pair with v_readlane (no memory access and
     // therefore no s_waitcnt vmcnt(0) inside the pair loop, which would drain the tile prefetch)
     f32x2 Areg = f2(0.f);
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const float dti = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
+            sdt += dti;
             y[i] = Dv * du[i];
             dd[i] = f2(dti, dti * du[i]);
         }
@@ -151,6 +157,15 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             for (int i = 0; i < SC_S; ++i) y[i] *= zz[i] * cad_sigmoid(zz[i]);
         }
         if (act) sc_store<T, SC_S, VEC>(o_row, p0, L, rev, y);
+    }
+    if (a.hT && act && lane < NP) {
+        float* hp = a.hT + ((int64_t)e * SB + sb) * N + 2 * lane;
+        hp[0] = carry[0];
+        if (2 * lane + 1 < N) hp[1] = carry[1];
+    }
+    if (a.sum_dt) {  // wave-uniform
+        sdt = wave_sum_dpp(sdt);
+        if (act && lane == 0) a.sum_dt[(int64_t)e * SB + sb] = sdt;
     }
 }
 

@@ -20,7 +20,7 @@ from typing import Optional
 
 import torch
 
-from . import mixer, ops
+from . import mixer, ops, seqpar
 
 
 def _w(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -34,7 +34,8 @@ def _scan_inputs(xz: torch.Tensor, m, split: int, rev_lo: int, rev_hi: int, act:
     E = E2 // 2
     T = SB * L
     N, R = m.d_state, m.dt_rank
-    xc = ops.causal_conv1d(xz[:E], m.conv1d.weight, m.conv1d.bias, split, rev_lo, rev_hi)
+    conv = seqpar.causal_conv1d if seqpar.active() else ops.causal_conv1d
+    xc = conv(xz[:E], m.conv1d.weight, m.conv1d.bias, split, rev_lo, rev_hi)
     dbc = torch.mm(_w(m.x_proj.weight, act), xc.view(E, T)).view(R + 2 * N, SB, L)
     delta = torch.mm(_w(m.dt_proj.weight, act), dbc[:R].reshape(R, T)).view(E, SB, L)
     A = -torch.exp(m.A_log.float())
@@ -67,22 +68,23 @@ def bimamba_tframe(hn: torch.Tensor, mamba_fwd, mamba_rev, strategy: Optional[st
     act = hn.dtype
     x2d = hn.reshape(T, D)
     split = B if (S == 2 and strand_swap) else SB
-    if mixer.can_use(mamba_fwd, mamba_rev, strategy):  # released-model configuration: hand-scheduled fwd/bwd
+    scan_multi = seqpar.selective_scan_multi if seqpar.active() else ops.selective_scan_multi
+    if not seqpar.active() and mixer.can_use(mamba_fwd, mamba_rev, strategy):  # released-model configuration
         return mixer.bimamba_mixer(hn, mamba_fwd, mamba_rev, split)
     xz_f = _in_proj(mamba_fwd, x2d, SB, L, act)
     E = xz_f.shape[0] // 2
     set_f = _scan_inputs(xz_f, mamba_fwd, split, 0, 1, act)
     if mamba_rev is None:
-        y_f = ops.selective_scan_multi([set_f], xz_f[E:], split, [(0, 1)])[0]
+        y_f = scan_multi([set_f], xz_f[E:], split, [(0, 1)])[0]
         return _out_proj(mamba_fwd, y_f, None, act).view(S, B, L, D)
     tied_in = mamba_rev.in_proj.weight is mamba_fwd.in_proj.weight and mamba_rev.in_proj.bias is mamba_fwd.in_proj.bias
     xz_r = xz_f if tied_in else _in_proj(mamba_rev, x2d, SB, L, act)
     set_r = _scan_inputs(xz_r, mamba_rev, split, 1, 0, act)
     if tied_in:  # both parameter sets share the gate z: ONE launch runs the forward- and reverse-direction scans
-        y_f, y_r = ops.selective_scan_multi([set_f, set_r], xz_f[E:], split, [(0, 1), (1, 0)])
+        y_f, y_r = scan_multi([set_f, set_r], xz_f[E:], split, [(0, 1), (1, 0)])
     else:
-        y_f = ops.selective_scan_multi([set_f], xz_f[E:], split, [(0, 1)])[0]
-        y_r = ops.selective_scan_multi([set_r], xz_r[E:], split, [(1, 0)])[0]
+        y_f = scan_multi([set_f], xz_f[E:], split, [(0, 1)])[0]
+        y_r = scan_multi([set_r], xz_r[E:], split, [(1, 0)])[0]
     strategy = strategy or "add"
     if strategy == "add":
         tied_out = (mamba_rev.out_proj.weight is mamba_fwd.out_proj.weight and mamba_fwd.out_proj.bias is None

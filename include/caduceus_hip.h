@@ -175,7 +175,10 @@ int cad_conv1d_bwd_multi(const cad_conv1d_bwd_args* sets, int nsets, void* strea
  * floating-point operation order), which is what keeps RC-equivariance bit-exact.
  * u, delta, z, out: (E, SB, L) dtype.  A: (E, N) fp32 (= -exp(A_log)).  Bm, Cm: (N, SB, L) dtype.
  * D, delta_bias: (E) fp32.  chunk_state: fp32 buffer of cad_scan_state_floats() elements (the running state at
- * every chunk start, needed by the backward), or NULL for inference. */
+ * every chunk start, needed by the backward), or NULL for inference.
+ * Optional state carries, (E, SB, N) fp32, NULL = absent: h0 = state entering the row's first logical position (default 0),
+ * hT = state after its last position (written); sum_dt (E, SB) = sum of dt over the row (written).  They make a row
+ * a segment of a longer sequence (sequence-parallel / chunk-pipelined scans: caduceus_amd/seqpar.py). */
 typedef struct {
     const void* u;
     const void* delta;
@@ -191,6 +194,9 @@ typedef struct {
     int E, N;
     int rev_lo, rev_hi;
     int dtype;
+    const float* h0;
+    float* hT;
+    float* sum_dt;
 } cad_scan_args;
 int cad_scan_fwd(const cad_scan_args* a, void* stream);
 /* Same, for nsets (1 or 2) independent parameter sets of identical shape in ONE launch -- the mamba_fwd and mamba_rev
@@ -204,7 +210,8 @@ int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
  * slot k is WRITTEN (plain coalesced stores, no atomics, no zeroing needed) with the sum over the channels of workgroup
  * k; cad_reduce_partials folds the slots (fp32 accumulation) into the final (N,SB,L) gradient.
  * chunk_state: as written by the forward.  out: the forward's (gated) output, required when z != NULL: the gate gradient
- * uses y = out / silu(z) instead of re-accumulating y (dz is 0 where z == 0 exactly). */
+ * uses y = out / silu(z) instead of re-accumulating y (dz is 0 where z == 0 exactly).
+ * Optional carries (E, SB, N) fp32: dhT = gradient w.r.t. the forward's hT (default 0), dh0 = gradient w.r.t. h0 (written). */
 typedef struct {
     const void* u;
     const void* delta;
@@ -230,6 +237,8 @@ typedef struct {
     int rev_lo, rev_hi;
     int dtype;
     int n_partials;
+    const float* dhT;
+    float* dh0;
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);

@@ -1,0 +1,82 @@
+"""sequence-parallel Caduceus.  Two gloo processes on CPU (kernels from the host emulator)
+each hold half of every sequence; logits, loss and every parameter gradient must match the single-process run."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden_model
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup_model(name):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    from build_emu import build_emu
+    from caduceus_amd import CaduceusConfig, CaduceusForMaskedLM, _lib
+    _lib.use_library_for_testing(build_emu())
+    cfg, sd, rec = load_golden_model(name)
+    model = CaduceusForMaskedLM(CaduceusConfig(**cfg, pad_token_id=4))
+    model.load_state_dict(sd)
+    return model.train(), rec
+
+
+def _long_batch(rec, L):
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(7, 11, (2, L), generator=g)
+    labels = ids.clone()
+    labels[torch.rand(2, L, generator=g) > 0.3] = 4
+    return ids, labels
+
+
+def _worker(rank, world, port, out_dir, name, L):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from caduceus_amd import seqpar
+    from caduceus_amd.dp import BucketedGradReducer
+    model, rec = _setup_model(name)
+    reducer = BucketedGradReducer(model.parameters(), average=False)  # partial sums over each rank's tokens
+    ids, labels = _long_batch(rec, L)
+    seg = slice(rank * L // world, (rank + 1) * L // world)
+    reducer.zero_grad()
+    with seqpar.sequence_parallel():
+        logits = model(ids[:, seg]).logits
+        loss = seqpar.masked_lm_loss(logits, labels[:, seg], ignore_index=4)
+    loss.backward()
+    reducer.finish()
+    total = loss.detach().clone()
+    dist.all_reduce(total)
+    torch.save({"logits": logits.detach(), "loss": total, "grads": {n: p.grad.clone() for n, p in model.named_parameters()}},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,L", [("ps_fused", 1100), ("ph_fused", 96)])
+def test_sequence_parallel_matches_single_process(tmp_path, name, L):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), name, L), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    model, rec = _setup_model(name)
+    ids, labels = _long_batch(rec, L)
+    out = model(ids, labels=labels)
+    out.loss.backward()
+    logits = torch.cat([p["logits"] for p in parts], 1)
+    torch.testing.assert_close(logits, out.logits.detach(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(parts[0]["loss"], out.loss.detach(), rtol=1e-5, atol=1e-6)
+    for n, p in model.named_parameters():
+        scale = max(1.0, float(p.grad.abs().max()))
+        torch.testing.assert_close(parts[0]["grads"][n], p.grad, rtol=2e-3, atol=2e-4 * scale, msg=lambda m, n=n: f"{n}: {m}")
+        assert torch.equal(parts[0]["grads"][n], parts[1]["grads"][n]), n
