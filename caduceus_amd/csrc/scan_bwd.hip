@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         Areg = f2(a.A[e * N + n0], (n0 + 1 < N) ? a.A[e * N + n0 + 1] : 0.f);
     }
     f32x2 carryG = f2(0.f);  // lane np: G flowing out of the later chunk into this one, for pair np
-    if (a.dhT && lane < NP) {
+    if (a.dhT && act && lane < NP) {  // padding waves (E % SC_W != 0) must not inject a state gradient
         const float* gp = a.dhT + ((int64_t)e * SB + sb) * N + 2 * lane;
         carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
     }

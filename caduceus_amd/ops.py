@@ -256,6 +256,68 @@ def selective_scan(u, delta, A, Bm, Cm, D, z, delta_bias, split: int, rev_lo: in
     return selective_scan_multi([(u, delta, A, Bm, Cm, D, delta_bias)], z, split, [(rev_lo, rev_hi)])[0]
 
 
+class _ScanStateful(torch.autograd.Function):
+    """One parameter set over a row SEGMENT: (u, delta, A, Bm, Cm, D, z, delta_bias, h0) -> (out, hT).  h0 / hT are the
+    (E, SB, N) fp32 states entering / leaving the segment along each row's direction; both are differentiable, so
+    consecutive segments chain through plain autograd (chunk-pipelined scans over sequences that do not fit at once, and
+    the building block of caduceus_amd/seqpar.py)."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, bias, h0, split, rev_lo, rev_hi):
+        lib = L.get_lib()
+        u, delta, Bm, Cm = u.contiguous(), delta.contiguous(), Bm.contiguous(), Cm.contiguous()
+        z = None if z is None else z.contiguous()
+        E, SB, Lq = u.shape
+        N = A.shape[1]
+        Af, Df, bf = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
+        h0f = None if h0 is None else h0.float().contiguous()
+        out = torch.empty_like(u)
+        hT = torch.empty((E, SB, N), dtype=torch.float32, device=u.device)
+        state = torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
+        stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, out, state, h0f, hT)
+        a = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf), L.ptr(out),
+                       L.ptr(state), SB, Lq, split, E, N, rev_lo, rev_hi, L.dtype_code(u.dtype), L.ptr(h0f), L.ptr(hT), None)
+        L.check(lib.cad_scan_fwd(C.byref(a), stream), "cad_scan_fwd")
+        ctx.save_for_backward(u, delta, Af, Bm, Cm, Df, z, bf, state, out)
+        ctx.meta = (split, rev_lo, rev_hi, A.dtype, D.dtype, bias.dtype, h0 is not None)
+        ctx.mark_non_differentiable()
+        return out, hT
+
+    @staticmethod
+    def backward(ctx, dout, dhT):
+        lib = L.get_lib()
+        u, delta, Af, Bm, Cm, Df, z, bf, state, fout = ctx.saved_tensors
+        split, rev_lo, rev_hi, Adt, Ddt, bdt, has_h0 = ctx.meta
+        E, SB, Lq = u.shape
+        N = Af.shape[1]
+        dout = torch.zeros_like(u) if dout is None else dout.contiguous()
+        dhT = None if dhT is None else dhT.float().contiguous()
+        du, ddelta = torch.empty_like(u), torch.empty_like(u)
+        dz = None if z is None else torch.empty_like(u)
+        dA, dD, dbias = torch.zeros_like(Af), torch.zeros_like(Df), torch.zeros_like(bf)
+        npart = lib.cad_scan_bwd_partials(E)
+        dBC = torch.empty((2, npart, N, SB, Lq), dtype=u.dtype, device=u.device)
+        dh0 = torch.empty((E, SB, N), dtype=torch.float32, device=u.device)
+        stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dBC, dD, dbias, dhT, dh0)
+        a = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
+                          L.ptr(dout), L.ptr(fout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
+                          L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N, rev_lo, rev_hi,
+                          L.dtype_code(u.dtype), npart, L.ptr(dhT), L.ptr(dh0))
+        L.check(lib.cad_scan_bwd(C.byref(a), stream), "cad_scan_bwd")
+        n = dBC[0, 0].numel()
+        dB, dC = torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device), \
+            torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device)
+        for src, dst in ((dBC[0], dB), (dBC[1], dC)):
+            L.check(lib.cad_reduce_partials(L.ptr(src), npart, n, L.ptr(dst), L.dtype_code(u.dtype), stream),
+                    "cad_reduce_partials")
+        return (du, ddelta, dA.to(Adt), dB, dC, dD.to(Ddt), dz, dbias.to(bdt), dh0 if has_h0 else None, None, None, None)
+
+
+def selective_scan_stateful(u, delta, A, Bm, Cm, D, z, delta_bias, h0, split: int, rev_lo: int, rev_hi: int):
+    """Segment scan with state carries: returns (out, hT).  See _ScanStateful."""
+    return _ScanStateful.apply(u, delta, A, Bm, Cm, D, z, delta_bias, h0, int(split), int(rev_lo), int(rev_hi))
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # selective scan, token-major kernels
 # ------------------------------------------------------------------------------------------------------------------

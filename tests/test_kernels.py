@@ -303,3 +303,42 @@ def test_causal_conv1d_two_sets(backend, case, dtype):
         torch.testing.assert_close(grads[i][0], wi.grad.view(E, K), rtol=1e-4, atol=1e-4 * max(1.0, float(wi.grad.abs().max())))
         torch.testing.assert_close(grads[i][1], bi.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(bi.grad.abs().max())))
     torch.testing.assert_close(dx.float(), dx_ref, **(FP32 if dtype == torch.float32 else BF16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cut", [512, 700, 37])
+def test_scan_state_carries_chain_segments(backend, dtype, cut):
+    """h0 / hT / dhT / dh0 of cad_scan_fwd / cad_scan_bwd: a row scanned as two chained segments (each direction gets
+    the segments in its own order) equals the row scanned at once, outputs and every gradient."""
+    name, dev = backend
+    E, SB, L, N = 5, 2, 1100, 16
+    t = _scan_inputs(E, SB, L, N, 31, dev, dtype)
+    order = ("u", "delta", "A", "B", "C", "D", "z", "bias")
+    act = {"u", "delta", "B", "C", "z"}
+    mk = lambda: [leaf(t[k], dev, dtype if k in act else torch.float32) for k in order]
+    w = t["w"].to(dev)
+    ref_in = mk()
+    ref = ops.selective_scan(*ref_in, 1, 0, 1)          # row 0 left-to-right, row 1 right-to-left
+    (ref.float() * w).sum().backward()
+    ins = mk()
+    u, d, A, B, C, D, z, b = ins
+    seg = lambda x, s: x[..., s]
+    lo, hi = slice(0, cut), slice(cut, L)
+    outs = {}
+    for row, rev in ((0, 0), (1, 1)):
+        first, second = (lo, hi) if rev == 0 else (hi, lo)  # the segment that holds the row's logical start first
+        r = slice(row, row + 1)
+        f = lambda x, s: x[:, r][..., s]
+        o1, h = ops.selective_scan_stateful(f(u, first), f(d, first), A, f(B, first), f(C, first), D, f(z, first), b, None,
+                                            1, rev, rev)
+        o2, _ = ops.selective_scan_stateful(f(u, second), f(d, second), A, f(B, second), f(C, second), D, f(z, second), b,
+                                            h, 1, rev, rev)
+        outs[row] = torch.cat([o1, o2], -1) if rev == 0 else torch.cat([o2, o1], -1)
+    out = torch.cat([outs[0], outs[1]], 1)
+    (out.float() * w).sum().backward()
+    tol = FP32 if dtype == torch.float32 else BF16
+    torch.testing.assert_close(out.float(), ref.float(), **tol)
+    for k, a_, r_ in zip(order, ins, ref_in):
+        scale = max(1.0, float(r_.grad.abs().max()))
+        torch.testing.assert_close(a_.grad.float(), r_.grad.float(), rtol=tol["rtol"], atol=tol["atol"] * scale,
+                                   msg=lambda m, k=k: f"d{k}: {m}")
