@@ -86,9 +86,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const float dti = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
-            sdt += dti;
             y[i] = Dv * du[i];
             dd[i] = f2(dti, dti * du[i]);
+        }
+        if (a.sum_dt) {  // wave-uniform; only the sequence-parallel / segmented callers ask for it
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) sdt += dd[i][0];
         }
         // running state at this chunk's start (first slot of the chunk); a mid-chunk state (second slot) is written per pair
         float* st_base = a.chunk_state ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + SLOTS * c) * NP * 2 : nullptr;
