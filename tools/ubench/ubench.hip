@@ -41,6 +41,32 @@ __global__ void ub(float* out, long long* cyc, int iters, float seed) {
         if (KIND == 15) BODY("v_cvt_pk_bf16_f32 %0, %0, %1", "v_cvt_pk_bf16_f32 %1, %1, %2", "v_cvt_pk_bf16_f32 %2, %2, %3", "v_cvt_pk_bf16_f32 %3, %3, %4", "v_cvt_pk_bf16_f32 %4, %4, %5", "v_cvt_pk_bf16_f32 %5, %5, %6", "v_cvt_pk_bf16_f32 %6, %6, %7", "v_cvt_pk_bf16_f32 %7, %7, %0");
         if (KIND == 16) BODY("v_exp_f16 %0, %0", "v_exp_f16 %1, %1", "v_exp_f16 %2, %2", "v_exp_f16 %3, %3", "v_exp_f16 %4, %4", "v_exp_f16 %5, %5", "v_exp_f16 %6, %6", "v_exp_f16 %7, %7");
         if (KIND == 17) BODY("v_ldexp_f32 %0, %0, %1", "v_ldexp_f32 %1, %1, %2", "v_ldexp_f32 %2, %2, %3", "v_ldexp_f32 %3, %3, %4", "v_ldexp_f32 %4, %4, %5", "v_ldexp_f32 %5, %5, %6", "v_ldexp_f32 %6, %6, %7", "v_ldexp_f32 %7, %7, %0");
+        if (KIND == 20)  // fma, four distinct registers per instruction (register-file port / bank pressure as in real code)
+            asm volatile(REP8("v_fma_f32 v40, v41, v42, v43\n\tv_fma_f32 v44, v45, v46, v47\n\tv_fma_f32 v48, v49, v50, v51\n\t"
+                              "v_fma_f32 v52, v53, v54, v55\n\tv_fma_f32 v41, v44, v49, v54\n\tv_fma_f32 v45, v48, v53, v42\n\t"
+                              "v_fma_f32 v49, v52, v43, v46\n\tv_fma_f32 v53, v40, v47, v50\n\t")
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        if (KIND == 21)  // fma with all operands in the same bank (register index mod 4 equal)
+            asm volatile(REP8("v_fma_f32 v40, v44, v48, v52\n\tv_fma_f32 v56, v60, v64, v68\n\tv_fma_f32 v44, v48, v52, v56\n\t"
+                              "v_fma_f32 v60, v64, v68, v40\n\tv_fma_f32 v48, v52, v56, v60\n\tv_fma_f32 v64, v68, v40, v44\n\t"
+                              "v_fma_f32 v52, v56, v60, v64\n\tv_fma_f32 v68, v40, v44, v48\n\t")
+                         ::: "v40", "v44", "v48", "v52", "v56", "v60", "v64", "v68");
+        if (KIND == 22)  // pk_fma, distinct register pairs
+            asm volatile(REP8("v_pk_fma_f32 v[40:41], v[42:43], v[44:45], v[46:47]\n\tv_pk_fma_f32 v[48:49], v[50:51], v[52:53], v[54:55]\n\t"
+                              "v_pk_fma_f32 v[56:57], v[58:59], v[60:61], v[62:63]\n\tv_pk_fma_f32 v[64:65], v[66:67], v[68:69], v[70:71]\n\t"
+                              "v_pk_fma_f32 v[42:43], v[48:49], v[58:59], v[68:69]\n\tv_pk_fma_f32 v[50:51], v[56:57], v[66:67], v[44:45]\n\t"
+                              "v_pk_fma_f32 v[58:59], v[64:65], v[46:47], v[52:53]\n\tv_pk_fma_f32 v[66:67], v[40:41], v[54:55], v[60:61]\n\t")
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                             "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
+        if (KIND == 23)  // mul, distinct registers
+            asm volatile(REP8("v_mul_f32 v40, v41, v42\n\tv_mul_f32 v43, v44, v45\n\tv_mul_f32 v46, v47, v48\n\tv_mul_f32 v49, v50, v51\n\t"
+                              "v_mul_f32 v41, v43, v47\n\tv_mul_f32 v44, v46, v50\n\tv_mul_f32 v47, v49, v42\n\tv_mul_f32 v50, v40, v45\n\t")
+                         ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
+        if (KIND == 24)  // fma with an SGPR operand + 2 distinct VGPRs
+            asm volatile(REP8("v_fma_f32 v40, v41, %0, v43\n\tv_fma_f32 v44, v45, %0, v47\n\tv_fma_f32 v48, v49, %0, v51\n\t"
+                              "v_fma_f32 v52, v53, %0, v55\n\tv_fma_f32 v41, v44, %0, v54\n\tv_fma_f32 v45, v48, %0, v42\n\t"
+                              "v_fma_f32 v49, v52, %0, v46\n\tv_fma_f32 v53, v40, %0, v50\n\t")
+                         :: "s"(sc) : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
     }
     long long t1 = __builtin_readcyclecounter();
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1] + lds[la & 1023];
@@ -70,8 +96,13 @@ void run(const char* name, int per_body, int waves_per_simd) {
 }
 
 int main() {
-    for (int w = 1; w <= 2; ++w) {
+    for (int w = 1; w <= 4; w *= 2) {
         run<0>("v_fma_f32", 8, w);
+        run<20>("v_fma_f32 4 distinct regs", 8, w);
+        run<21>("v_fma_f32 same-bank regs", 8, w);
+        run<24>("v_fma_f32 sgpr + distinct", 8, w);
+        run<22>("v_pk_fma_f32 distinct pairs", 8, w);
+        run<23>("v_mul_f32 distinct regs", 8, w);
         run<4>("v_mul_f32", 8, w);
         run<9>("v_fma_f32 (sgpr src)", 8, w);
         run<6>("v_mov_b32", 8, w);
