@@ -138,7 +138,7 @@ __device__ __forceinline__ void wave_scan_fwd(f32x2& A, f32x2& H) {
 
 // Inclusive scan in REVERSE lane order (lane 63 first): (A, G) of lane j is the composition of lanes 63..j.
 // Row-local steps use DPP row_shl; the two cross-row steps have no DPP broadcast in this direction and go through
-// ds_bpermute (__shfl) / readlane.
+// v_readlane + masked updates.
 __device__ __forceinline__ void wave_scan_rev(f32x2& A, f32x2& G, int lane) {
 #ifdef CAD_EMU
     SC_COMBINE(A, G, dpp_row_shl<1>(1.f, A[0]), dpp_row_shl<1>(1.f, A[1]), dpp_row_shl<1>(0.f, G[0]), dpp_row_shl<1>(0.f, G[1]));
@@ -158,17 +158,27 @@ __device__ __forceinline__ void wave_scan_rev(f32x2& A, f32x2& G, int lane) {
         A = f2(a0, a1);
     }
 #endif
-    // after the row-local steps the FIRST lane of every row holds its whole row; fold the later rows in
-    {   // rows 0 and 2 <- total of the next row
-        const int src = (((lane >> 4) + 1) << 4) & 63;
-        const float a0 = __shfl(A[0], src), a1 = __shfl(A[1], src), g0 = __shfl(G[0], src), g1 = __shfl(G[1], src);
-        const bool ok = ((lane >> 4) & 1) == 0;
-        SC_COMBINE(A, G, ok ? a0 : 1.f, ok ? a1 : 1.f, ok ? g0 : 0.f, ok ? g1 : 0.f);
+    // after the row-local steps the FIRST lane of every row holds its whole row; fold the later rows in.  The totals
+    // travel through SGPRs (v_readlane) and are applied under a lane mask: no LDS round trip (ds_bpermute costs
+    // ~150 cycles of exposed latency twice per scan).
+    {   // rows 0 and 2 <- total of the next row (lanes 16 / 48)
+        const f32x2 a16 = readlane2(A, 16), g16 = readlane2(G, 16), a48 = readlane2(A, 48), g48 = readlane2(G, 48);
+        const int row = lane >> 4;
+        if (row == 0) {
+            G = A * g16 + G;
+            A = A * a16;
+        }
+        if (row == 2) {
+            G = A * g48 + G;
+            A = A * a48;
+        }
     }
     {   // rows 0 and 1 <- total of rows 2..3 (now at lane 32)
-        const float a0 = __shfl(A[0], 32), a1 = __shfl(A[1], 32), g0 = __shfl(G[0], 32), g1 = __shfl(G[1], 32);
-        const bool ok = lane < 32;
-        SC_COMBINE(A, G, ok ? a0 : 1.f, ok ? a1 : 1.f, ok ? g0 : 0.f, ok ? g1 : 0.f);
+        const f32x2 a32 = readlane2(A, 32), g32 = readlane2(G, 32);
+        if (lane < 32) {
+            G = A * g32 + G;
+            A = A * a32;
+        }
     }
 }
 
