@@ -168,6 +168,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const f32x2 Av = readlane2(Areg, np);
             const f32x2 A2 = Av * f2(CAD_LOG2E);
             const f32x2 hin = readlane2(hin_reg, np);
+            // C of this pair is needed by the reverse scan AND the gradient step: read it once, before the forward scan
+            f32x2 Cv[SC_S];
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) Cv[i] = ld2(tC + 2 * i);
             // 1. forward recompute: serial totals, wave scan, then the true h_i
             f32x2 av[SC_S], hs[SC_S];
             f32x2 acc_h = f2(0.f);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // 2. reverse scan of G
             f32x2 RG = f2(0.f);
 #pragma unroll
-            for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (ld2(tC + 2 * i) * splat_lo(ee[i]) + RG);
+            for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (Cv[i] * splat_lo(ee[i]) + RG);
             f32x2 QA = acc_a, QG = RG;
             wave_scan_rev(QA, QG, lane);
             const f32x2 fa = f2(dpp_wave_shl1(1.f, QA[0]), dpp_wave_shl1(1.f, QA[1]));
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 #pragma unroll
             for (int i = SC_S - 1; i >= 0; --i) {
                 const f32x2 Bv = ld2(tB + 2 * i);
-                const f32x2 g = ld2(tC + 2 * i) * splat_lo(ee[i]) + G;
+                const f32x2 g = Cv[i] * splat_lo(ee[i]) + G;
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
