@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     T* dCg = (T*)a.dC + (int64_t)blockIdx.x * part_stride;
 
     StageRegs<T, SC_SV(SC_S)> st;
-    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw;
+    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw;  // d / g / z / out stay in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
         sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, 0, N, SB, sb, base, L, rev);
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
         sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
         if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
+        if (z_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
         sc_stage_store<T, SC_S>(st, smem, rev);
     }
     __syncthreads();
@@ -106,14 +107,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         float ddt[SC_S], ddu[SC_S];
         f32x2 dd[SC_S], ee[SC_S];  // (dt, dt * u) and (dy, u)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
-#ifndef SC_BWD_PREFETCH
         if (c != nchunks - 1) {
             sc_load_raw<T, SC_S, VEC>(u_row, p0, L, rev, u_raw);
             sc_load_raw<T, SC_S, VEC>(d_row, p0, L, rev, d_raw);
             sc_load_raw<T, SC_S, VEC>(g_row, p0, L, rev, g_raw);
             if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
+            if (z_row) sc_load_raw<T, SC_S, VEC>(o_row, p0, L, rev, o_raw);
         }
-#endif
         {
             float uu[SC_S], dt[SC_S], dy[SC_S];
             sc_unpack<T, SC_S>(u_raw, rev, uu);
@@ -144,14 +144,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
             hin_reg = f2(stp[0], stp[1]);
         }
-#ifdef SC_BWD_PREFETCH
-        if (c > 0) {  // prefetch the item vectors of the next (earlier) chunk
-            sc_load_raw<T, SC_S, VEC>(u_row, p0 - SC_CHUNK, L, rev, u_raw);
-            sc_load_raw<T, SC_S, VEC>(d_row, p0 - SC_CHUNK, L, rev, d_raw);
-            sc_load_raw<T, SC_S, VEC>(g_row, p0 - SC_CHUNK, L, rev, g_raw);
-            if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0 - SC_CHUNK, L, rev, z_raw);
-        }
-#endif
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);
@@ -273,15 +265,17 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             if (SC_SLAB_BUFS == 1) __syncthreads();  // the slab is rewritten by the next pair
         }
-        // per-item outputs of this chunk (delta / z / dout are re-read: still L2-resident, keeps VGPRs free)
-        float dl[SC_S];
-        sc_load<T, SC_S, VEC>(d_row, p0, L, rev, dl);
+        // per-item outputs of this chunk, from the raw vectors loaded at the chunk's start (no re-reads)
+        {
+            float dl[SC_S];
+            sc_unpack<T, SC_S>(d_raw, rev, dl);
 #pragma unroll
-        for (int i = 0; i < SC_S; ++i) {
-            const float xraw = dl[i] + bias;
-            const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
-            ddt[i] = (p0 + i < L) ? ddt[i] * sg : 0.f;
-            dbacc += ddt[i];
+            for (int i = 0; i < SC_S; ++i) {
+                const float xraw = dl[i] + bias;
+                const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
+                ddt[i] = (p0 + i < L) ? ddt[i] * sg : 0.f;
+                dbacc += ddt[i];
+            }
         }
         if (act) {
             sc_store<T, SC_S, VEC>(du_row, p0, L, rev, ddu);
@@ -290,9 +284,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         if (dz_row) {
             // out = y * z * sigmoid(z)  =>  y * sigmoid(z) = out / z ;  dz = dout * y * sigmoid(z) * (1 + z (1 - sigmoid(z)))
             float zz[SC_S], go[SC_S], oo[SC_S];
-            sc_load<T, SC_S, VEC>(z_row, p0, L, rev, zz);
-            sc_load<T, SC_S, VEC>(g_row, p0, L, rev, go);
-            sc_load<T, SC_S, VEC>(o_row, p0, L, rev, oo);
+            sc_unpack<T, SC_S>(z_raw, rev, zz);
+            sc_unpack<T, SC_S>(g_raw, rev, go);
+            sc_unpack<T, SC_S>(o_raw, rev, oo);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const float sg = cad_sigmoid(zz[i]);
