@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     T* dCg = (T*)a.dC + (int64_t)blockIdx.x * part_stride;
 
     StageRegs<T, SC_SV(SC_S)> st;
-    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw;  // d / g / z / out stay in registers until the chunk's epilogue
+    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw;  // d_raw stays in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
         sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, 0, N, SB, sb, base, L, rev);
@@ -96,6 +96,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     if (a.dhT && act && lane < NP) {  // padding waves (E % SC_W != 0) must not inject a state gradient
         const float* gp = a.dhT + ((int64_t)e * SB + sb) * N + 2 * lane;
         carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
+    }
+    f32x2 hin_next = f2(0.f);
+    if (lane < NP) {
+        const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + nchunks - 1) * NP + lane) * 2;
+        hin_next = f2(stp[0], stp[1]);
     }
     f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
     float dDacc = 0.f, dbacc = 0.f;
@@ -120,10 +125,19 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             sc_unpack<T, SC_S>(d_raw, rev, dt);
             sc_unpack<T, SC_S>(g_raw, rev, dy);
             if (z_row) {
-                float zz[SC_S];
+                // gate: dy <- dout * silu(z), and the gate gradient right away (it needs nothing from the scan):
+                // out = y * z * sigmoid(z)  =>  y * sigmoid(z) = out / z ;  dz = dout * y * sigmoid(z) * (1 + z (1 - sigmoid(z)))
+                float zz[SC_S], oo[SC_S], dzv[SC_S];
                 sc_unpack<T, SC_S>(z_raw, rev, zz);
+                sc_unpack<T, SC_S>(o_raw, rev, oo);
 #pragma unroll
-                for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
+                for (int i = 0; i < SC_S; ++i) {
+                    const float sg = cad_sigmoid(zz[i]);
+                    const float ys = (zz[i] == 0.f) ? 0.f : oo[i] * cad_rcp(zz[i]);
+                    dzv[i] = dy[i] * ys * (1.f + zz[i] * (1.f - sg));
+                    dy[i] *= zz[i] * sg;
+                }
+                if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
             }
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
@@ -138,11 +152,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 ee[i] = f2(dyi, uu[i]);
             }
         }
-        // running states of all pairs at this chunk's start (saved by the forward): lane np fetches pair np
-        f32x2 hin_reg = f2(0.f);
-        if (lane < NP) {
-            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + lane) * 2;
-            hin_reg = f2(stp[0], stp[1]);
+        // running states of all pairs at this chunk's start (saved by the forward): lane np holds pair np; the next
+        // (earlier) chunk's states are fetched now and land while this chunk computes
+        const f32x2 hin_reg = hin_next;
+        if (lane < NP && c > 0) {
+            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c - 1) * NP + lane) * 2;
+            hin_next = f2(stp[0], stp[1]);
         }
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
@@ -160,10 +175,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const f32x2 Av = readlane2(Areg, np);
             const f32x2 A2 = Av * f2(CAD_LOG2E);
             const f32x2 hin = readlane2(hin_reg, np);
-            // C of this pair is needed by the reverse scan AND the gradient step: read it once, before the forward scan
-            f32x2 Cv[SC_S];
+            // B and C of this pair are each needed twice (recompute / gradient step, reverse scan / gradient step): read
+            // them from the LDS tile once, up front
+            f32x2 Cv[SC_S], Bw[SC_S];
 #pragma unroll
-            for (int i = 0; i < SC_S; ++i) Cv[i] = ld2(tC + 2 * i);
+            for (int i = 0; i < SC_S; ++i) Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
             // 1. forward recompute: serial totals, wave scan, then the true h_i
             f32x2 av[SC_S], hs[SC_S];
             f32x2 acc_h = f2(0.f);
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 av[i] = exp2_2(splat_lo(dd[i]) * A2);
-                hs[i] = splat_hi(dd[i]) * ld2(tB + 2 * i);  // b_i
+                hs[i] = splat_hi(dd[i]) * Bw[i];  // b_i
                 acc_h = av[i] * acc_h + hs[i];
             }
             f32x2 PA = acc_a, PH = acc_h;
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             f32x2 dAp = f2(0.f);
 #pragma unroll
             for (int i = SC_S - 1; i >= 0; --i) {
-                const f32x2 Bv = ld2(tB + 2 * i);
+                const f32x2 Bv = Bw[i];
                 const f32x2 g = Cv[i] * splat_lo(ee[i]) + G;
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             if (SC_SLAB_BUFS == 1) __syncthreads();  // the slab is rewritten by the next pair
         }
-        // per-item outputs of this chunk, from the raw vectors loaded at the chunk's start (no re-reads)
+        // per-item outputs of this chunk; delta from the raw vector loaded at the chunk's start (no re-read)
         {
             float dl[SC_S];
             sc_unpack<T, SC_S>(d_raw, rev, dl);
@@ -280,20 +296,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         if (act) {
             sc_store<T, SC_S, VEC>(du_row, p0, L, rev, ddu);
             sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
-        }
-        if (dz_row) {
-            // out = y * z * sigmoid(z)  =>  y * sigmoid(z) = out / z ;  dz = dout * y * sigmoid(z) * (1 + z (1 - sigmoid(z)))
-            float zz[SC_S], go[SC_S], oo[SC_S];
-            sc_unpack<T, SC_S>(z_raw, rev, zz);
-            sc_unpack<T, SC_S>(g_raw, rev, go);
-            sc_unpack<T, SC_S>(o_raw, rev, oo);
-#pragma unroll
-            for (int i = 0; i < SC_S; ++i) {
-                const float sg = cad_sigmoid(zz[i]);
-                const float ys = (zz[i] == 0.f) ? 0.f : oo[i] * cad_rcp(zz[i]);
-                go[i] = go[i] * ys * (1.f + zz[i] * (1.f - sg));
-            }
-            if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, go);
         }
     }
     if (a.dh0 && act && lane < NP) {  // gradient w.r.t. the state entering the row
