@@ -27,7 +27,9 @@ struct ScanBwdSets {
 #define SC_S SC_S_BWD
 #define SC_W SC_W_BWD
 #define SC_CHUNK (64 * SC_S)
-#define ACC_TILE (SC_S * 64 * 2)        // floats per (wave, tensor) region, layout [item i][lane j][state s]
+#define ACC_ISTR (64 * 2 + 2)           // floats between items: 128 + 2 pad, so that the flush's two half-chunks
+                                        // (items i and i + 4 of neighbouring lanes) fall into different LDS banks
+#define ACC_TILE (SC_S * ACC_ISTR)      // floats per (wave, tensor) region, layout [item i][lane j][state s]
 #define ACC_BUF (SC_W * 2 * ACC_TILE)  // floats per buffer: [wave][dB,dC][ACC_TILE]
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
-            float* aB = acc + (SC_SLAB_BUFS == 2 ? buf : 0) * ACC_BUF + wave * 2 * ACC_TILE + lane * 2;  // (i, s) at aB[i * 128 + s]: 8-byte stride
+            float* aB = acc + (SC_SLAB_BUFS == 2 ? buf : 0) * ACC_BUF + wave * 2 * ACC_TILE + lane * 2;  // (i, s) at aB[i * ACC_ISTR + s]: 8-byte stride
             float* aC = aB + ACC_TILE;
             const int n0 = 2 * np;
             const f32x2 Av = readlane2(Areg, np);
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * splat_lo(ee[i]);
-                *(f32x2*)(aB + i * 128) = dBv;  // ds_write_b64, conflict-free
-                *(f32x2*)(aC + i * 128) = dCv;
+                *(f32x2*)(aB + i * ACC_ISTR) = dBv;  // ds_write_b64, conflict-free
+                *(f32x2*)(aC + i * ACC_ISTR) = dCv;
             }
             dAp = wave_sum2(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     float v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float* src = tile + (i0 + q) * 128 + j * 2 + s;
+                        const float* src = tile + (i0 + q) * ACC_ISTR + j * 2 + s;
                         float sum = 0.f;
 #pragma unroll
                         for (int w = 0; w < SC_W; ++w) sum += src[w * 2 * ACC_TILE];
