@@ -256,8 +256,13 @@ struct __attribute__((aligned(sizeof(T) * SV >= 16 ? 16 : 8))) StVec {
 template <typename T, int SV>
 struct StageRegs {
     StVec<T, SV> s0, s1;
+    bool ok0, ok1;  // VEC path: the vector was read from a clamped (always valid) address; zero it at conversion time
 };
 
+// VEC path: the load itself is UNCONDITIONAL (clamped address) and nothing is computed on its result here, so the
+// compiler places the s_waitcnt at the conversion in sc_stage_store, one whole pair-step later.  (With a conditional
+// load + zero-fill the compiler unpacks the bf16 halves inside the branch and waits for the load right there,
+// exposing the full L2 latency twice per pair-step on the staging waves.)
 template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const T* Bm, const T* Cm, int n0, int N,
                                               int64_t SB, int64_t sb, int64_t base, int64_t L, int rev) {
@@ -269,16 +274,16 @@ __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const T
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         StVec<T, SV>& dst = s ? r.s1 : r.s0;
-        const T* row = src + ((int64_t)(n0 + s) * SB + sb) * L;
         if constexpr (VEC) {
-            if (n0 + s < N && p0 < L) {
-                const int64_t l0 = rev ? (L - p0 - SV) : p0;
-                dst = *(const StVec<T, SV>*)(row + l0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < SV; ++j) dst.v[j] = from_f32<T>(0.f);
-            }
+            const bool ok = n0 + s < N && p0 < L;
+            const int ns = (n0 + s < N) ? n0 + s : n0;  // n0 < N always
+            const T* row = src + ((int64_t)ns * SB + sb) * L;
+            const int64_t l0 = (p0 < L) ? (rev ? (L - p0 - SV) : p0) : 0;
+            dst = *(const StVec<T, SV>*)(row + l0);
+            (s ? r.ok1 : r.ok0) = ok;
         } else {
+            const T* row = src + ((int64_t)(n0 + s) * SB + sb) * L;
+            (s ? r.ok1 : r.ok0) = true;
 #pragma unroll
             for (int j = 0; j < SV; ++j) {
                 const int64_t p = p0 + j;
@@ -304,7 +309,7 @@ __device__ __forceinline__ void sc_stage_store(const StageRegs<T, SC_SV(S)>& r, 
 #pragma unroll
     for (int j = 0; j < SV; ++j) {
         const int k = rev ? (SV - 1 - j) : j;
-        dst[2 * j] = to_f32(r.s0.v[k]);
-        dst[2 * j + 1] = to_f32(r.s1.v[k]);
+        dst[2 * j] = r.ok0 ? to_f32(r.s0.v[k]) : 0.f;
+        dst[2 * j + 1] = r.ok1 ? to_f32(r.s1.v[k]) : 0.f;
     }
 }
