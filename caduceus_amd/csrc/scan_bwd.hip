@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
         if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
         if (z_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
-        sc_stage_store<T, SC_S>(st, smem, rev);
+        sc_stage_store<T, SC_S, VEC>(st, smem, rev);
     }
     __syncthreads();
 
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             dAp = wave_sum2(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
-            if (more) sc_stage_store<T, SC_S>(st, smem + (buf ^ 1) * 2 * TILE, rev);
+            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev);
             __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             if (np == NP - 1 && c > 0) {
                 // the item vectors of the next (earlier) chunk: issued now, they land behind this pair's flush and the

@@ -259,10 +259,58 @@ struct StageRegs {
     bool ok0, ok1;  // VEC path: the vector was read from a clamped (always valid) address; zero it at conversion time
 };
 
-// VEC path: the load itself is UNCONDITIONAL (clamped address) and nothing is computed on its result here, so the
-// compiler places the s_waitcnt at the conversion in sc_stage_store, one whole pair-step later.  (With a conditional
-// load + zero-fill the compiler unpacks the bf16 halves inside the branch and waits for the load right there,
-// exposing the full L2 latency twice per pair-step on the staging waves.)
+// Asynchronous vector load into registers: issued through inline asm, so the compiler neither knows it is a load nor
+// waits for it; sc_stage_wait() below is the matching s_waitcnt, placed by hand right before the data is consumed one
+// pair-step later.  (A compiler-visible load is unpacked -- bf16 high halves -- right where it is issued, i.e. it is
+// waited for immediately, which exposes the full L2 latency on the staging waves every pair-step.)  Loads the compiler
+// issues itself stay correct: an unknown extra load in flight can only make its vmcnt waits longer, never too short.
+template <typename V>
+__device__ __forceinline__ void sc_async_load(V& dst, const void* p) {
+#ifdef CAD_EMU
+    dst = *(const V*)p;
+#else
+    static_assert(sizeof(V) == 8 || sizeof(V) == 16 || sizeof(V) == 32, "vector sizes of the staging path");
+    if constexpr (sizeof(V) == 8) {
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        u2 v;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+        dst = __builtin_bit_cast(V, v);
+    } else if constexpr (sizeof(V) == 16) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        u4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+        dst = __builtin_bit_cast(V, v);
+    } else {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        struct P { u4 a, b; } v;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                     : "=&v"(v.a), "=&v"(v.b) : "v"(p) : "memory");
+        dst = __builtin_bit_cast(V, v);
+    }
+#endif
+}
+template <typename V>
+__device__ __forceinline__ void sc_async_wait(V& a, V& b) {
+#ifndef CAD_EMU
+    if constexpr (sizeof(V) == 8) {
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        u2 x = __builtin_bit_cast(u2, a), y = __builtin_bit_cast(u2, b);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x), "+v"(y)::"memory");
+        a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y);
+    } else if constexpr (sizeof(V) == 16) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        u4 x = __builtin_bit_cast(u4, a), y = __builtin_bit_cast(u4, b);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x), "+v"(y)::"memory");
+        a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y);
+    } else {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        struct P { u4 a, b; };
+        P x = __builtin_bit_cast(P, a), y = __builtin_bit_cast(P, b);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x.a), "+v"(x.b), "+v"(y.a), "+v"(y.b)::"memory");
+        a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y);
+    }
+#endif
+}
 template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const T* Bm, const T* Cm, int n0, int N,
                                               int64_t SB, int64_t sb, int64_t base, int64_t L, int rev) {
@@ -279,7 +327,7 @@ __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const T
             const int ns = (n0 + s < N) ? n0 + s : n0;  // n0 < N always
             const T* row = src + ((int64_t)ns * SB + sb) * L;
             const int64_t l0 = (p0 < L) ? (rev ? (L - p0 - SV) : p0) : 0;
-            dst = *(const StVec<T, SV>*)(row + l0);
+            sc_async_load(dst, row + l0);
             (s ? r.ok1 : r.ok0) = ok;
         } else {
             const T* row = src + ((int64_t)(n0 + s) * SB + sb) * L;
@@ -297,12 +345,13 @@ __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const T
     }
 }
 
-template <typename T, int S>
-__device__ __forceinline__ void sc_stage_store(const StageRegs<T, SC_SV(S)>& r, float* tiles /* B tile, C tile follows */,
+template <typename T, int S, bool VEC>
+__device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float* tiles /* B tile, C tile follows */,
                                                int rev) {
     constexpr int SV = SC_SV(S);
     const int t = threadIdx.x;
     if (t >= 256) return;
+    if constexpr (VEC) sc_async_wait(r.s0, r.s1);
     float* tile = tiles + (t >> 7) * SC_TILE(S);
     const int tok = (t & 127) * SV;  // position inside the chunk
     float* dst = tile + (tok / S) * SC_ROW(S) + (tok % S) * 2;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, 0, N, SB, sb, 0, L, rev);
     sc_load_raw<T, SC_S, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
     sc_load_raw<T, SC_S, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
-    sc_stage_store<T, SC_S>(st, smem, rev);
+    sc_stage_store<T, SC_S, VEC>(st, smem, rev);
     __syncthreads();
 
     f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
                 const f32x2 h = ha[i] * h0 + hh[i];
                 y[i] += dot2(ld2(tC + 2 * i), h);
             }
-            if (more) sc_stage_store<T, SC_S>(st, smem + (buf ^ 1) * 2 * TILE, rev);
+            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev);
             __syncthreads();
         }
         if (z_row) {
