@@ -75,10 +75,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     T* dCg = (T*)a.dC + (int64_t)blockIdx.x * part_stride;
 
     StageRegs<T, SC_SV(SC_S)> st;
+    const StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
     ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw, d_next;  // d_raw stays in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
-        sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, 0, N, SB, sb, base, L, rev);
+        sc_stage_load<T, SC_S, VEC>(st, sctx, 0, N, base, L, rev);
         sc_load_raw<T, SC_S, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
         sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
         sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
-                sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
+                sc_stage_load<T, SC_S, VEC>(st, sctx, nn, N, nb, L, rev);
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;

@@ -311,26 +311,43 @@ __device__ __forceinline__ void sc_async_wait(V& a, V& b) {
     }
 #endif
 }
-template <typename T, int S, bool VEC>
-__device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const T* Bm, const T* Cm, int n0, int N,
-                                              int64_t SB, int64_t sb, int64_t base, int64_t L, int rev) {
-    constexpr int SV = SC_SV(S);
+// Per-thread constants of the staging path, computed once per kernel: the thread's tensor base (+ its row sb) and its
+// first token inside a chunk.  Keeps the per-pair address arithmetic to one uniform multiply and two adds.
+template <typename T>
+struct StageCtx {
+    const T* src;        // Bm or Cm, advanced to row (state 0, sb)
+    int64_t row_stride;  // SB * L: distance between consecutive states
+    int tok;             // first token of this thread inside a chunk
+    bool on;             // threads 0..255 stage
+};
+template <typename T, int S>
+__device__ __forceinline__ StageCtx<T> sc_stage_ctx(const T* Bm, const T* Cm, int64_t SB, int64_t sb, int64_t L) {
     const int t = threadIdx.x;
-    if (t >= 256) return;
-    const T* src = (t >> 7) ? Cm : Bm;
-    const int64_t p0 = base + (int64_t)(t & 127) * SV;
+    StageCtx<T> c;
+    c.on = t < 256;
+    c.src = ((t >> 7) & 1 ? Cm : Bm) + sb * L;
+    c.row_stride = SB * L;
+    c.tok = (t & 127) * SC_SV(S);
+    return c;
+}
+
+template <typename T, int S, bool VEC>
+__device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const StageCtx<T>& c, int n0, int N, int64_t base,
+                                              int64_t L, int rev) {
+    constexpr int SV = SC_SV(S);
+    if (!c.on) return;
+    const int64_t p0 = base + c.tok;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         StVec<T, SV>& dst = s ? r.s1 : r.s0;
         if constexpr (VEC) {
             const bool ok = n0 + s < N && p0 < L;
             const int ns = (n0 + s < N) ? n0 + s : n0;  // n0 < N always
-            const T* row = src + ((int64_t)ns * SB + sb) * L;
             const int64_t l0 = (p0 < L) ? (rev ? (L - p0 - SV) : p0) : 0;
-            sc_async_load(dst, row + l0);
+            sc_async_load(dst, c.src + ns * c.row_stride + l0);
             (s ? r.ok1 : r.ok0) = ok;
         } else {
-            const T* row = src + ((int64_t)(n0 + s) * SB + sb) * L;
+            const T* row = c.src + (int64_t)(n0 + s) * c.row_stride;
             (s ? r.ok1 : r.ok0) = true;
 #pragma unroll
             for (int j = 0; j < SV; ++j) {

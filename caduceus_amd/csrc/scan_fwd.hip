@@ -42,8 +42,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     // software pipeline: the B/C tile of the NEXT (chunk, pair) and the u/delta/z vectors of the NEXT chunk are in
     // flight (registers) while the current pair is computed.
     StageRegs<T, SC_SV(SC_S)> st;
+    const StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
     ScVec<T, SC_S> u_raw, d_raw, z_raw;
-    sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, 0, N, SB, sb, 0, L, rev);
+    sc_stage_load<T, SC_S, VEC>(st, sctx, 0, N, 0, L, rev);
     sc_load_raw<T, SC_S, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
     sc_load_raw<T, SC_S, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
     sc_stage_store<T, SC_S, VEC>(st, smem, rev);
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base + SC_CHUNK;
-                sc_stage_load<T, SC_S, VEC>(st, Bm, Cm, nn, N, SB, sb, nb, L, rev);
+                sc_stage_load<T, SC_S, VEC>(st, sctx, nn, N, nb, L, rev);
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
