@@ -27,6 +27,7 @@ struct ScanBwdSets {
 #define SC_S SC_S_BWD
 #define SC_W SC_W_BWD
 #define SC_CHUNK (64 * SC_S)
+#define SC_DY(i) (((i) & 1) ? splat_hi(dy2[(i) >> 1]) : splat_lo(dy2[(i) >> 1]))  // dy of item i on both halves
 #define ACC_ISTR (64 * 2 + 2)           // floats between items: 128 + 2 pad, so that the flush's two half-chunks
                                         // (items i and i + 4 of neighbouring lanes) fall into different LDS banks
 #define ACC_TILE (SC_S * ACC_ISTR)      // floats per (wave, tensor) region, layout [item i][lane j][state s]
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 
     StageRegs<T, SC_SV(SC_S)> st;
     const StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
-    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw, d_next;  // d_raw stays in registers until the chunk's epilogue
+    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw;  // u_raw / d_raw stay in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
         sc_stage_load<T, SC_S, VEC>(st, sctx, 0, N, base, L, rev);
@@ -112,8 +113,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     for (int64_t c = nchunks - 1; c >= 0; --c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
-        float ddt[SC_S], ddu[SC_S];
-        f32x2 dd[SC_S], ee[SC_S];  // (dt, dt * u) and (dy, u)
+        float ddt[SC_S], gBs[SC_S];   // sum over the states of g * h_{i-1} * a * A  and of  <g, B>
+        f32x2 dd[SC_S];               // (dt, dt * u) per item
+        f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
         {
             float uu[SC_S], dt[SC_S], dy[SC_S];
@@ -141,11 +143,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
                 ddt[i] = 0.f;
-                ddu[i] = dyi * Dv;
+                gBs[i] = 0.f;
                 dDacc += dyi * uu[i];
                 dd[i] = f2(dti, dti * uu[i]);
                 sum_dt += dti;
-                ee[i] = f2(dyi, uu[i]);
+                dy2[i >> 1][i & 1] = dyi;
             }
         }
         // running states of all pairs at this chunk's start (saved by the forward): lane np holds pair np; the next
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // 2. reverse scan of G
             f32x2 RG = f2(0.f);
 #pragma unroll
-            for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (Cv[i] * splat_lo(ee[i]) + RG);
+            for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (Cv[i] * SC_DY(i) + RG);
             f32x2 QA = acc_a, QG = RG;
             wave_scan_rev(QA, QG, lane);
             const f32x2 fa = f2(dpp_wave_shl1(1.f, QA[0]), dpp_wave_shl1(1.f, QA[1]));
@@ -216,21 +218,41 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 #pragma unroll
             for (int i = SC_S - 1; i >= 0; --i) {
                 const f32x2 Bv = Bw[i];
-                const f32x2 g = Cv[i] * splat_lo(ee[i]) + G;
+                const f32x2 g = Cv[i] * SC_DY(i) + G;
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
                 const float gB = dot2(g, Bv);
-                ddt[i] += dot2(t, Av) + ee[i][1] * gB;
-                ddu[i] += dd[i][0] * gB;
+                ddt[i] += dot2(t, Av);
+                gBs[i] += gB;
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
-                const f32x2 dCv = hs[i] * splat_lo(ee[i]);
+                const f32x2 dCv = hs[i] * SC_DY(i);
                 *(f32x2*)(aB + i * ACC_ISTR) = dBv;  // ds_write_b64, conflict-free
                 *(f32x2*)(aC + i * ACC_ISTR) = dCv;
             }
             dAp = wave_sum2(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
+            if (np == NP - 1) {
+                // per-item outputs of this chunk (all states folded in): u / delta from the raw vectors loaded at the
+                // chunk's start; done before the barrier so that the prefetch below may overwrite those registers
+                float uu[SC_S], dl[SC_S], du[SC_S];
+                sc_unpack<T, SC_S>(u_raw, rev, uu);
+                sc_unpack<T, SC_S>(d_raw, rev, dl);
+#pragma unroll
+                for (int i = 0; i < SC_S; ++i) {
+                    const float xraw = dl[i] + bias;
+                    const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
+                    const float dyi = dy2[i >> 1][i & 1];
+                    du[i] = dd[i][0] * gBs[i] + dyi * Dv;
+                    ddt[i] = (p0 + i < L) ? (ddt[i] + uu[i] * gBs[i]) * sg : 0.f;
+                    dbacc += ddt[i];
+                }
+                if (act) {
+                    sc_store<T, SC_S, VEC>(du_row, p0, L, rev, du);
+                    sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
+                }
+            }
             if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev);
             __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             if (np == NP - 1 && c > 0) {
@@ -238,7 +260,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 // chunk epilogue instead of stalling the next chunk's start
                 const int64_t pn = p0 - SC_CHUNK;
                 sc_load_raw<T, SC_S, VEC>(u_row, pn, L, rev, u_raw);
-                sc_load_raw<T, SC_S, VEC>(d_row, pn, L, rev, d_next);
+                sc_load_raw<T, SC_S, VEC>(d_row, pn, L, rev, d_raw);
                 sc_load_raw<T, SC_S, VEC>(g_row, pn, L, rev, g_raw);
                 if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, pn, L, rev, z_raw);
                 if (z_row) sc_load_raw<T, SC_S, VEC>(o_row, pn, L, rev, o_raw);
@@ -287,23 +309,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             if (SC_SLAB_BUFS == 1) __syncthreads();  // the slab is rewritten by the next pair
         }
-        // per-item outputs of this chunk; delta from the raw vector loaded at the chunk's start (no re-read)
-        {
-            float dl[SC_S];
-            sc_unpack<T, SC_S>(d_raw, rev, dl);
-#pragma unroll
-            for (int i = 0; i < SC_S; ++i) {
-                const float xraw = dl[i] + bias;
-                const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
-                ddt[i] = (p0 + i < L) ? ddt[i] * sg : 0.f;
-                dbacc += ddt[i];
-            }
-        }
-        if (act) {
-            sc_store<T, SC_S, VEC>(du_row, p0, L, rev, ddu);
-            sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
-        }
-        d_raw = d_next;
     }
     if (a.dh0 && act && lane < NP) {  // gradient w.r.t. the state entering the row
         float* gp = a.dh0 + ((int64_t)e * SB + sb) * N + 2 * lane;
