@@ -325,7 +325,7 @@ __device__ __forceinline__ StageCtx<T> sc_stage_ctx(const T* Bm, const T* Cm, in
     const int t = threadIdx.x;
     StageCtx<T> c;
     c.on = t < 256;
-    c.src = ((t >> 7) & 1 ? Cm : Bm) + sb * L;
+    c.src = (cad_uniform(t >> 7) & 1 ? Cm : Bm) + sb * L;  // wave-uniform: the tensor changes every two waves -> SGPRs
     c.row_stride = SB * L;
     c.tok = (t & 127) * SC_SV(S);
     return c;
