@@ -325,7 +325,7 @@ __device__ __forceinline__ StageCtx<T> sc_stage_ctx(const T* Bm, const T* Cm, in
     const int t = threadIdx.x;
     StageCtx<T> c;
     c.on = t < 256;
-    c.src = (cad_uniform(t >> 7) & 1 ? Cm : Bm) + sb * L;  // wave-uniform: the tensor changes every two waves -> SGPRs
+    c.src = ((t >> 7) & 1 ? Cm : Bm) + sb * L;
     c.row_stride = SB * L;
     c.tok = (t & 127) * SC_SV(S);
     return c;
@@ -371,15 +371,11 @@ __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float*
     if constexpr (VEC) sc_async_wait(r.s0, r.s1);
     float* tile = tiles + (t >> 7) * SC_TILE(S);
     const int tok = (t & 127) * SV;  // position inside the chunk
-    float* dst = tile + (tok / S) * SC_ROW(S) + (tok % S) * 2;  // 16-byte aligned: rows and half rows are multiples of 16 B
-    static_assert(SV % 2 == 0 && (SC_ROW(S) * 4) % 16 == 0, "vectorised tile store");
-    // vectors read from a clamped address (state or positions out of range) are zeroed; what was read there is other,
-    // finite input data, so a multiplicative mask is exact
-    const float m0 = r.ok0 ? 1.f : 0.f, m1 = r.ok1 ? 1.f : 0.f;
+    float* dst = tile + (tok / S) * SC_ROW(S) + (tok % S) * 2;
 #pragma unroll
-    for (int j = 0; j < SV; j += 2) {  // two tokens x two states = one ds_write_b128
-        const int k0 = rev ? (SV - 1 - j) : j, k1 = rev ? (SV - 2 - j) : j + 1;
-        const f32x4 v = {to_f32(r.s0.v[k0]) * m0, to_f32(r.s1.v[k0]) * m1, to_f32(r.s0.v[k1]) * m0, to_f32(r.s1.v[k1]) * m1};
-        *(f32x4*)(dst + 2 * j) = v;
+    for (int j = 0; j < SV; ++j) {
+        const int k = rev ? (SV - 1 - j) : j;
+        dst[2 * j] = r.ok0 ? to_f32(r.s0.v[k]) : 0.f;
+        dst[2 * j + 1] = r.ok1 ? to_f32(r.s1.v[k]) : 0.f;
     }
 }
