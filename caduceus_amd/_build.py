@@ -20,7 +20,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = LIB) -> str:
+def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = LIB, extra_flags=()) -> str:
     """Cross-compiles every kernel for gfx950 (works without a GPU).  Objects are built in parallel.
     `defines` / `out` build tuning variants (e.g. ("SC_S=8",)) next to the default library for A/B measurements."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -30,7 +30,7 @@ def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = 
     objdir = os.path.join(HERE, "build", os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
-    flags += [f"-D{d}" for d in defines]
+    flags += [f"-D{d}" for d in defines] + list(extra_flags)
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
