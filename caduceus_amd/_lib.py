@@ -83,7 +83,7 @@ class ScanTmArgs(C.Structure):
 class MlmArgs(C.Structure):
     _fields_ = [("bases", _p), ("rc_flags", _p), ("lengths", _p), ("input_ids", _p), ("labels", _p), ("B", _i64),
                 ("L", _i64), ("ld_bases", _i64), ("seed", C.c_uint64), ("offset", C.c_uint64), ("thr_mask", C.c_uint32),
-                ("pad_id", _i), ("mask_id", _i), ("unk_id", _i), ("n_id", _i), ("vocab", _i), ("base_ids", _i * 4)]
+                ("pad_id", _i), ("mask_id", _i), ("unk_id", _i), ("n_id", _i), ("vocab", _i), ("base_ids", _i * 4), ("row_ids", _p)]
 
 
 class LmHeadArgs(C.Structure):

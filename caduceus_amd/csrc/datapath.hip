@@ -75,7 +75,8 @@ __global__ void tokenize_mlm_kernel(cad_mlm_args a) {
         }
         int in_id = id, label = a.pad_id;
         if (a.labels && q >= 0) {
-            const Philox r = philox4x32_10((uint32_t)p, (uint32_t)((uint64_t)p >> 32), (uint32_t)b, (uint32_t)a.offset,
+            const uint32_t sid = (uint32_t)(a.row_ids ? a.row_ids[b] : b);  // random stream of this row
+            const Philox r = philox4x32_10((uint32_t)p, (uint32_t)((uint64_t)p >> 32), sid, (uint32_t)a.offset,
                                            (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
             if (r.c[0] < a.thr_mask) {              // Bernoulli(mlm_probability): a target
                 label = id;

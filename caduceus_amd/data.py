@@ -107,16 +107,18 @@ class FastaInterval:
 
 def tokenize_mlm(bases: torch.Tensor, lengths: Optional[torch.Tensor], rc_flags: Optional[torch.Tensor], L_out: int, *,
                  mlm: bool = True, mlm_probability: float = 0.15, seed: int = 0, offset: int = 0, pad_id: int = 4,
-                 mask_id: int = 3, unk_id: int = 6, n_id: int = 11, vocab: int = 12, base_ids=(7, 8, 9, 10)):
-    """bases: (B, ld) uint8 on the kernel device (raw ASCII).  Returns (input_ids, labels or None), int64 (B, L_out)."""
+                 mask_id: int = 3, unk_id: int = 6, n_id: int = 11, vocab: int = 12, base_ids=(7, 8, 9, 10),
+                 row_ids: Optional[torch.Tensor] = None):
+    """bases: (B, ld) uint8 on the kernel device (raw ASCII).  Returns (input_ids, labels or None), int64 (B, L_out).
+    row_ids (B) int64: the random stream of each row (default: the row number)."""
     lib = L.get_lib()
     B, ld = bases.shape
     ids = torch.empty((B, L_out), dtype=torch.int64, device=bases.device)
     labels = torch.empty_like(ids) if mlm else None
-    stream = L.stream_and_check(bases, lengths, rc_flags, ids, labels)
+    stream = L.stream_and_check(bases, lengths, rc_flags, ids, labels, row_ids)
     a = L.MlmArgs(L.ptr(bases), L.ptr(rc_flags), L.ptr(lengths), L.ptr(ids), L.ptr(labels), B, L_out, ld, seed, offset,
                   lib.cad_mlm_threshold(float(mlm_probability)), pad_id, mask_id, unk_id, n_id, vocab,
-                  (C.c_int * 4)(*base_ids))
+                  (C.c_int * 4)(*base_ids), L.ptr(row_ids))
     L.check(lib.cad_tokenize_mlm(C.byref(a), stream), "cad_tokenize_mlm")
     return ids, labels
 
@@ -185,9 +187,10 @@ class HG38Dataset(torch.utils.data.Dataset):
             rc[j] = 1 if (self.fasta.rc_aug and self.fasta.coin_flip()) else 0
         dev = self.device
         bases = stage.to(dev, non_blocking=True)
-        self._calls += 1
+        self._calls += 1  # the mask of a sample is keyed on (its index, how many batches this object has served)
         ids, labels = tokenize_mlm(bases, lens.to(dev), rc.to(dev), Lp, mlm=self.mlm,
-                                   mlm_probability=self.mlm_probability, seed=self.seed, offset=self._calls, **self._ids)
+                                   mlm_probability=self.mlm_probability, seed=self.seed, offset=self._calls,
+                                   row_ids=torch.as_tensor(list(indices), dtype=torch.int64).to(dev), **self._ids)
         if self.mlm:
             return ids, labels  # add_eos is appended and stripped again by the reference (mlm.py:10): no net effect
         if self.add_eos:

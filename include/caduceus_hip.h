@@ -316,8 +316,9 @@ int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream);
  * (src/dataloaders/utils/rc.py:17-26) for rows whose rc flag is set, replace_value(N -> [PAD]) (:212), left padding to L,
  * and mlm_getitem (src/dataloaders/utils/mlm.py:4-32): Bernoulli(p) targets, of which 80 % become [MASK], 10 % a random
  * id in [0, vocab), 10 % stay; labels = [PAD] everywhere else.  labels == NULL: tokenisation only.
- * Random numbers are Philox4x32-10 with key = seed and counter = (position, row, offset): reproducible, independent of the
- * launch geometry, restated bit for bit by oracle/data_oracle.py (they are NOT torch's CPU generator stream, so batches
+ * Random numbers are Philox4x32-10 with key = seed and counter = (position, stream id, offset), where the stream id of
+ * row b is row_ids[b] (e.g. the global sample index, so a sample's mask does not depend on where in which batch -- or
+ * in which loader worker -- it lands) or b when row_ids is NULL: reproducible, independent of the launch geometry, restated bit for bit by oracle/data_oracle.py (they are NOT torch's CPU generator stream, so batches
  * are equal to the reference's in distribution, not sample by sample).
  *   bases: (B, ld_bases) bytes, row b holds lengths[b] bases (lengths NULL: L each); rc_flags: (B) bytes or NULL.
  *   thr_mask = cad_mlm_threshold(mlm_probability); base_ids = ids of A, C, G, T. */
@@ -332,6 +333,7 @@ typedef struct {
     uint32_t thr_mask;
     int pad_id, mask_id, unk_id, n_id, vocab;
     int base_ids[4];
+    const int64_t* row_ids;
 } cad_mlm_args;
 int cad_tokenize_mlm(const cad_mlm_args* a, void* stream);
 uint32_t cad_mlm_threshold(double probability);

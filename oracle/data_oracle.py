@@ -6,7 +6,7 @@ Follows the reference's per-sample Python:
   * reverse complement      -- /root/reference/src/dataloaders/utils/rc.py:5-26 (A<->T, C<->G, case kept, others unchanged)
   * N -> [PAD], left padding -- /root/reference/src/dataloaders/datasets/hg38_dataset.py:176-212
   * MLM corruption          -- /root/reference/src/dataloaders/utils/mlm.py:4-32, with the uniforms drawn from
-                               Philox4x32-10 (key = seed, counter = (pos_lo, pos_hi, row, offset)) exactly as
+                               Philox4x32-10 (key = seed, counter = (pos_lo, pos_hi, row stream id, offset)) exactly as
                                caduceus_amd/csrc/datapath.hip does, so the comparison is bit-exact.
   * interval arithmetic     -- hg38_dataset.py:41-89 (`hg38_interval`)
 Pinned by tests/golden/datapath.npz, generated from the reference's own functions by oracle/gen_golden_data.py.
@@ -50,7 +50,7 @@ def mlm_threshold(p: float) -> int:
     return 0xFFFFFFFF if t >= 4294967295.0 else int(t)
 
 
-def tokenize_mlm(seqs, L, rc_flags=None, mlm_probability=0.15, seed=0, offset=0, mlm=True, vocab=12):
+def tokenize_mlm(seqs, L, rc_flags=None, mlm_probability=0.15, seed=0, offset=0, mlm=True, vocab=12, row_ids=None):
     """seqs: list of str (each <= L).  Returns (input_ids, labels) int64 (B, L); labels None when mlm is False."""
     B = len(seqs)
     ids = np.full((B, L), PAD, dtype=np.int64)
@@ -66,7 +66,8 @@ def tokenize_mlm(seqs, L, rc_flags=None, mlm_probability=0.15, seed=0, offset=0,
     if not mlm:
         return ids, None
     pos = np.arange(L, dtype=np.uint64)[None, :]
-    row = np.arange(B, dtype=np.uint64)[:, None]
+    row = (np.arange(B, dtype=np.uint64) if row_ids is None else
+           np.asarray(row_ids, dtype=np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF))[:, None]
     r0, r1, r2, r3 = philox4x32_10(pos & np.uint64(0xFFFFFFFF), pos >> np.uint64(32), row, np.uint64(offset & 0xFFFFFFFF),
                                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     target = valid & (r0 < np.uint64(mlm_threshold(mlm_probability)))

@@ -118,6 +118,30 @@ def test_tokenize_mlm_kernel_bit_exact(backend, B, L, ragged, mlm):
         assert labels is None
 
 
+def test_tokenize_mlm_row_streams(backend):
+    """row_ids select the random stream of a row: bit-exact vs the oracle, and a sample's corruption does not depend on
+    which batch row it occupies."""
+    _, dev = backend
+    rng = np.random.default_rng(5)
+    B, L = 4, 512
+    lens = np.full(B, L)
+    raw, seqs = _rows(B, L, rng, lens)
+    rid = np.array([1000003, 7, 2 ** 31 + 5, 0], dtype=np.int64)
+    kw = dict(mlm=True, mlm_probability=0.15, seed=99, offset=3)
+    ids, labels = cdata.tokenize_mlm(torch.from_numpy(raw).to(dev), None, None, L, row_ids=torch.from_numpy(rid).to(dev), **kw)
+    want_ids, want_labels = do.tokenize_mlm(seqs, L, mlm_probability=0.15, seed=99, offset=3, row_ids=rid)
+    assert np.array_equal(ids.cpu().numpy(), want_ids) and np.array_equal(labels.cpu().numpy(), want_labels)
+    perm = np.array([2, 0, 3, 1])
+    ids_p, labels_p = cdata.tokenize_mlm(torch.from_numpy(raw[perm].copy()).to(dev), None, None, L,
+                                         row_ids=torch.from_numpy(rid[perm].copy()).to(dev), **kw)
+    assert torch.equal(ids_p, ids[torch.from_numpy(perm).to(dev)]) and torch.equal(labels_p, labels[torch.from_numpy(perm).to(dev)])
+    # default stream = the row number
+    ids_d, _ = cdata.tokenize_mlm(torch.from_numpy(raw).to(dev), None, None, L, **kw)
+    ids_r, _ = cdata.tokenize_mlm(torch.from_numpy(raw).to(dev), None, None, L,
+                                  row_ids=torch.arange(B, dtype=torch.int64, device=dev), **kw)
+    assert torch.equal(ids_d, ids_r) and not torch.equal(ids_d, ids)
+
+
 def test_dataset_end_to_end(backend, genome, tmp_path):
     """HG38Dataset over the synthetic genome: reference constructor, (data, target) contract, N -> pad, determinism."""
     _, dev = backend
@@ -138,8 +162,12 @@ def test_dataset_end_to_end(backend, genome, tmp_path):
     clean = np.asarray(do.tokenize(plain)); clean[clean == do.N_ID] = do.PAD
     tgt = (target[2] != do.PAD).cpu().numpy()
     assert np.array_equal(target[2].cpu().numpy()[tgt], clean[tgt])
-    keep = ~tgt
+    keep = ~tgt & (clean != do.PAD)  # an N (-> [PAD]) chosen as a target keeps the label [PAD], as in mlm.py
     assert np.array_equal(data[2].cpu().numpy()[keep], clean[keep])
+    # the corruption of a sample is keyed on its index, not on its row in the batch
+    ds3 = cdata.HG38Dataset("train", bed, path, max_length=1024, mlm=True, mlm_probability=0.15, device=dev, seed=3)
+    d3, t3 = ds3.batch(idx[::-1])
+    assert torch.equal(d3.flip(0), data) and torch.equal(t3.flip(0), target)
     one_d, one_t = ds2[0]
     assert one_d.shape == (1024,) and one_d.device.type == "cpu"
     clm = cdata.HG38Dataset("valid", bed, path, max_length=2048, mlm=False, add_eos=True, device=dev)
