@@ -71,6 +71,19 @@ __device__ __forceinline__ f32x2 splat_hi(f32x2 v) {
 }
 __device__ __forceinline__ f32x2 exp2_2(f32x2 v) { return f2(cad_exp2(v[0]), cad_exp2(v[1])); }
 __device__ __forceinline__ float dot2(f32x2 a, f32x2 b) { return a[0] * b[0] + a[1] * b[1]; }
+// acc + a . b as two scalar v_fmac.  Written in asm because the SLP vectoriser otherwise packs the dot products of two
+// neighbouring items into v_pk_* and pays for the transposition with 6 v_mov + 1 v_pk_mov per item pair (12
+// instructions per two items instead of 6; measured in the forward scan's output phase).  -fno-slp-vectorize gives the
+// same instruction count but lets the scheduler hoist the C-tile reads (256 VGPRs + spills instead of 215).
+__device__ __forceinline__ float dot2_acc(float acc, f32x2 a, f32x2 b) {
+#ifdef CAD_EMU
+    return __builtin_fmaf(a[1], b[1], __builtin_fmaf(a[0], b[0], acc));
+#else
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a[0]), "v"(b[0]));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a[1]), "v"(b[1]));
+    return acc;
+#endif
+}
 __device__ __forceinline__ f32x2 readlane2(f32x2 v, int l) { return f2(cad_readlane(v[0], l), cad_readlane(v[1], l)); }
 __device__ __forceinline__ float wave_sum1(float v) {
 #pragma unroll
@@ -319,6 +332,8 @@ struct StageCtx {
     int64_t row_stride;  // SB * L: distance between consecutive states
     int tok;             // first token of this thread inside a chunk
     bool on;             // threads 0..255 stage
+    const T* cur;        // sc_stage_seek: this thread's vector of state 0 in the chunk being staged (clamped address)
+    bool in;             // ... and whether it lies inside the sequence
 };
 template <typename T, int S>
 __device__ __forceinline__ StageCtx<T> sc_stage_ctx(const T* Bm, const T* Cm, int64_t SB, int64_t sb, int64_t L) {
@@ -328,7 +343,28 @@ __device__ __forceinline__ StageCtx<T> sc_stage_ctx(const T* Bm, const T* Cm, in
     c.src = ((t >> 7) & 1 ? Cm : Bm) + sb * L;
     c.row_stride = SB * L;
     c.tok = (t & 127) * SC_SV(S);
+    c.cur = c.src;
+    c.in = false;
     return c;
+}
+// Points the staging thread at the chunk starting at logical position `base` (VEC path).  Done once per chunk, so that
+// the per-pair sc_stage_issue is two address adds (the full address arithmetic costs ~40 instructions).
+template <typename T, int S>
+__device__ __forceinline__ void sc_stage_seek(StageCtx<T>& c, int64_t base, int64_t L, int rev) {
+    constexpr int SV = SC_SV(S);
+    const int64_t p0 = base + c.tok;
+    c.in = p0 < L;
+    c.cur = c.src + (c.in ? (rev ? (L - p0 - SV) : p0) : 0);
+}
+template <typename T, int S>
+__device__ __forceinline__ void sc_stage_issue(StageRegs<T, SC_SV(S)>& r, const StageCtx<T>& c, int n0, int N) {
+    if (!c.on) return;
+    const bool two = n0 + 1 < N;
+    const T* p = c.cur + n0 * c.row_stride;  // n0 < N always
+    sc_async_load(r.s0, p);
+    sc_async_load(r.s1, two ? p + c.row_stride : p);
+    r.ok0 = c.in;
+    r.ok1 = c.in && two;
 }
 
 template <typename T, int S, bool VEC>
@@ -372,6 +408,38 @@ __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float*
     float* tile = tiles + (t >> 7) * SC_TILE(S);
     const int tok = (t & 127) * SV;  // position inside the chunk
     float* dst = tile + (tok / S) * SC_ROW(S) + (tok % S) * 2;
+#ifndef CAD_EMU
+    if constexpr (VEC && sizeof(T) == 2 && SV % 4 == 0) {
+        // bf16 fast path on the raw dwords (the generic loop below costs ~7 instructions per stored float: per-element
+        // selects for `rev` and `ok`): reverse the token order with one select + one rotate per dword, zero a vector
+        // that came from a clamped address with one AND per dword, widen with shift / mask, store 16 bytes at a time.
+        constexpr int NW = SV / 2;
+        typedef uint32_t uw __attribute__((ext_vector_type(NW)));
+        const uw a = __builtin_bit_cast(uw, r.s0), b = __builtin_bit_cast(uw, r.s1);
+        const uint32_t rot = rev ? 16u : 0u;
+        const uint32_t rsel = __builtin_amdgcn_readfirstlane(rev ? ~0u : 0u);  // rev is wave-uniform: force SGPRs
+        const uint64_t rmask = ((uint64_t)rsel << 32) | rsel;
+        const uint32_t m0 = r.ok0 ? 0xFFFFFFFFu : 0u, m1 = r.ok1 ? 0xFFFFFFFFu : 0u;
+        uint32_t w0[NW], w1[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            // (a C++ select here is canonicalised into a dynamic vector index = a chain of 3 selects per dword)
+            uint32_t x, y;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(x) : "v"(a[i]), "v"(a[NW - 1 - i]), "s"(rmask));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(y) : "v"(b[i]), "v"(b[NW - 1 - i]), "s"(rmask));
+            w0[i] = __builtin_amdgcn_alignbit(x, x, rot) & m0;
+            w1[i] = __builtin_amdgcn_alignbit(y, y, rot) & m1;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {  // tokens 2i (low halves) and 2i + 1 (high halves), states 0 / 1 interleaved
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            u4 q;
+            q[0] = w0[i] << 16, q[1] = w1[i] << 16, q[2] = w0[i] & 0xFFFF0000u, q[3] = w1[i] & 0xFFFF0000u;
+            *(u4*)(dst + 4 * i) = q;
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < SV; ++j) {
         const int k = rev ? (SV - 1 - j) : j;

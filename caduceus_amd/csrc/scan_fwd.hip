@@ -11,11 +11,21 @@ struct ScanFwdSets {
 #define SC_S SC_S_FWD
 #define SC_W SC_W_FWD
 #define SC_CHUNK (64 * SC_S)
+// B/C tiles live in a ring of SC_RING_FWD LDS slots; a tile is staged SC_RING_FWD / 2 pairs ahead of its use and the
+// workgroup meets at a barrier once per SC_RING_FWD / 2 pairs (2: double buffer, one barrier per pair).
+#ifndef SC_OCC_FWD
+#define SC_OCC_FWD SC_OCC
+#endif
+#ifndef SC_RING_FWD
+#define SC_RING_FWD 8
+#endif
 
 template <typename T, bool VEC>
-__global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets sets) {
-    CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][SC_TILE]
+__global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwdSets sets) {
+    CAD_DYN_SMEM(float, smem);  // [SC_RING_FWD slots][B,C][SC_TILE]
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
+    constexpr int RING = SC_RING_FWD, AHEAD = RING / 2;
+    static_assert(RING >= 2 && (RING & (RING - 1)) == 0, "ring of 2^k tiles");
     constexpr int SLOTS = SC_CHUNK / SC_STATE_STEP;  // saved-state slots per forward chunk (1 or 2)
     const cad_scan_args& a = sets.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
@@ -42,12 +52,34 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
     // software pipeline: the B/C tile of the NEXT (chunk, pair) and the u/delta/z vectors of the NEXT chunk are in
     // flight (registers) while the current pair is computed.
     StageRegs<T, SC_SV(SC_S)> st;
-    const StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
+    StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
+    if constexpr (VEC) sc_stage_seek<T, SC_S>(sctx, 0, L, rev);
     ScVec<T, SC_S> u_raw, d_raw, z_raw;
-    sc_stage_load<T, SC_S, VEC>(st, sctx, 0, N, 0, L, rev);
+    const int ntiles = (int)nchunks * NP;
+    int s_np = 0;        // staging cursor: (chunk base, pair) of the next tile to stage
+    int64_t s_base = 0;
     sc_load_raw<T, SC_S, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
     sc_load_raw<T, SC_S, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
-    sc_stage_store<T, SC_S, VEC>(st, smem, rev);
+    // stage the tile of the cursor / move the cursor on (wave-uniform)
+#define SC_FWD_STAGE()                                                                 \
+    do {                                                                               \
+        if constexpr (VEC)                                                             \
+            sc_stage_issue<T, SC_S>(st, sctx, 2 * s_np, N);                            \
+        else                                                                           \
+            sc_stage_load<T, SC_S, VEC>(st, sctx, 2 * s_np, N, s_base, L, rev);        \
+    } while (0)
+#define SC_FWD_ADVANCE()                                                               \
+    do {                                                                               \
+        if (++s_np == NP) {                                                            \
+            s_np = 0, s_base += SC_CHUNK;                                              \
+            if constexpr (VEC) sc_stage_seek<T, SC_S>(sctx, s_base, L, rev);           \
+        }                                                                              \
+    } while (0)
+    for (int g = 0; g < AHEAD; ++g) {
+        SC_FWD_STAGE();
+        sc_stage_store<T, SC_S, VEC>(st, smem + g * 2 * TILE, rev);
+        SC_FWD_ADVANCE();
+    }
     __syncthreads();
 
     f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
@@ -101,14 +133,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
             st_base[lane * 2 + 1] = carry[1];
         }
         for (int np = 0; np < NP; ++np, ++tix) {
-            const int buf = tix & 1;
-            // prefetch the next tile: pair np+1 of this chunk, or pair 0 of the next chunk
-            const bool more = (np + 1 < NP) || (c + 1 < nchunks);
-            if (more) {
-                const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
-                const int64_t nb = (np + 1 < NP) ? base : base + SC_CHUNK;
-                sc_stage_load<T, SC_S, VEC>(st, sctx, nn, N, nb, L, rev);
-            }
+            const int buf = tix & (RING - 1);
+            // prefetch the tile AHEAD pairs from now (this chunk's or the next one's)
+            const bool more = tix + AHEAD < ntiles;
+            if (more) SC_FWD_STAGE();
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
             const f32x2 A2 = readlane2(Areg, np);
@@ -146,10 +174,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const f32x2 h = ha[i] * h0 + hh[i];
-                y[i] += dot2(ld2(tC + 2 * i), h);
+                y[i] = dot2_acc(y[i], ld2(tC + 2 * i), h);
             }
-            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev);
-            __syncthreads();
+            if (more) {
+                sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev);
+                SC_FWD_ADVANCE();
+            }
+            if (((tix + 1) & (AHEAD - 1)) == 0) __syncthreads();
         }
         if (z_row) {
             float zz[SC_S];
@@ -171,11 +202,29 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_fwd_kernel(ScanFwdSets
         sdt = wave_sum_dpp(sdt);
         if (act && lane == 0) a.sum_dt[(int64_t)e * SB + sb] = sdt;
     }
+#undef SC_FWD_STAGE
+#undef SC_FWD_ADVANCE
 }
 
 }  // namespace
 
 static_assert(SC_CHUNK == SC_STATE_STEP || SC_CHUNK == 2 * SC_STATE_STEP, "forward chunk = one or two state slots");
+
+// more than 64 KB of dynamic LDS has to be requested per kernel (once)
+#if defined(CAD_EMU)
+#define SC_FWD_BIG_LDS(kern, bytes) (void)0
+#else
+#define SC_FWD_BIG_LDS(kern, bytes)                                                                                  \
+    do {                                                                                                             \
+        static bool done = false;                                                                                    \
+        if ((bytes) > 65536 && !done) {                                                                              \
+            if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != \
+                hipSuccess)                                                                                          \
+                return CAD_ERR_LAUNCH;                                                                                 \
+            done = true;                                                                                             \
+        }                                                                                                            \
+    } while (0)
+#endif
 
 extern "C" int64_t cad_scan_chunk_len(void) { return SC_CHUNK; }
 
@@ -205,20 +254,26 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
                        (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm) % 16) == 0;
     CadProfScope prof(0, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const size_t shmem = (size_t)4 * SC_TILE(SC_S) * sizeof(float);
+    const size_t shmem = (size_t)SC_RING_FWD * 2 * SC_TILE(SC_S) * sizeof(float);
+#define SC_FWD_LAUNCH(T, V)                                                                                         \
+    do {                                                                                                            \
+        SC_FWD_BIG_LDS((scan_fwd_kernel<T, V>), shmem);                                                             \
+        CAD_LAUNCH((scan_fwd_kernel<T, V>), grid, block, shmem, stream, ks);                                        \
+    } while (0)
     if (a->dtype == CAD_F32) {
         if (vec)
-            CAD_LAUNCH((scan_fwd_kernel<float, true>), grid, block, shmem, stream, ks);
+            SC_FWD_LAUNCH(float, true);
         else
-            CAD_LAUNCH((scan_fwd_kernel<float, false>), grid, block, shmem, stream, ks);
+            SC_FWD_LAUNCH(float, false);
     } else if (a->dtype == CAD_BF16) {
         if (vec)
-            CAD_LAUNCH((scan_fwd_kernel<bf16_t, true>), grid, block, shmem, stream, ks);
+            SC_FWD_LAUNCH(bf16_t, true);
         else
-            CAD_LAUNCH((scan_fwd_kernel<bf16_t, false>), grid, block, shmem, stream, ks);
+            SC_FWD_LAUNCH(bf16_t, false);
     } else {
         return CAD_ERR_UNSUPPORTED;
     }
+#undef SC_FWD_LAUNCH
     return cad_after_launch();
 }
 
