@@ -76,11 +76,16 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     T* dCg = (T*)a.dC + (int64_t)blockIdx.x * part_stride;
 
     StageRegs<T, SC_SV(SC_S)> st;
-    const StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
+    StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
     ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw;  // u_raw / d_raw stay in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
-        sc_stage_load<T, SC_S, VEC>(st, sctx, 0, N, base, L, rev);
+        if constexpr (VEC) {
+            sc_stage_seek<T, SC_S>(sctx, base, L, rev);
+            sc_stage_issue<T, SC_S>(st, sctx, 0, N);
+        } else {
+            sc_stage_load<T, SC_S, VEC>(st, sctx, 0, N, base, L, rev);
+        }
         sc_load_raw<T, SC_S, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
         sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
         sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
@@ -113,7 +118,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     for (int64_t c = nchunks - 1; c >= 0; --c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
-        float ddt[SC_S], gBs[SC_S];   // sum over the states of g * h_{i-1} * a * A  and of  <g, B>
+        float ddt[SC_S];
+        f32x2 ddt2[SC_S], gBs2[SC_S];  // sums over the states of g * h_{i-1} * a * A and of <g, B>, even / odd states apart
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const bool ok = p0 + i < L;
                 const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
-                ddt[i] = 0.f;
-                gBs[i] = 0.f;
+                ddt2[i] = f2(0.f);
+                gBs2[i] = f2(0.f);
                 dDacc += dyi * uu[i];
                 dd[i] = f2(dti, dti * uu[i]);
                 sum_dt += dti;
@@ -163,7 +169,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
-                sc_stage_load<T, SC_S, VEC>(st, sctx, nn, N, nb, L, rev);
+                if constexpr (VEC) {
+                    if (nn == 0) sc_stage_seek<T, SC_S>(sctx, nb, L, rev);  // wave-uniform: once per chunk
+                    sc_stage_issue<T, SC_S>(st, sctx, nn, N);
+                } else {
+                    sc_stage_load<T, SC_S, VEC>(st, sctx, nn, N, nb, L, rev);
+                }
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
@@ -193,18 +204,19 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
             const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
             const f32x2 h0 = ea * hin + eh;  // state entering this lane's segment
+            // the true h_i (forward chain) and 2. the reverse scan of G (backward chain), interleaved: two independent
+            // serial v_pk_fma chains, each step of one fills the wait state the other needs between dependent packed ops
+            f32x2 RG = f2(0.f);
             {
                 f32x2 h = h0;
 #pragma unroll
                 for (int i = 0; i < SC_S; ++i) {
+                    const int r = SC_S - 1 - i;
                     h = av[i] * h + hs[i];
+                    RG = av[r] * (Cv[r] * SC_DY(r) + RG);
                     hs[i] = h;  // h_i
                 }
             }
-            // 2. reverse scan of G
-            f32x2 RG = f2(0.f);
-#pragma unroll
-            for (int i = SC_S - 1; i >= 0; --i) RG = av[i] * (Cv[i] * SC_DY(i) + RG);
             f32x2 QA = acc_a, QG = RG;
             wave_scan_rev(QA, QG, lane);
             const f32x2 fa = f2(dpp_wave_shl1(1.f, QA[0]), dpp_wave_shl1(1.f, QA[1]));
@@ -222,16 +234,15 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
-                const float gB = dot2(g, Bv);
-                ddt[i] += dot2(t, Av);
-                gBs[i] += gB;
+                pk_fma_acc(ddt2[i], t, Av);
+                pk_fma_acc(gBs2[i], g, Bv);
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * SC_DY(i);
                 *(f32x2*)(aB + i * ACC_ISTR) = dBv;  // ds_write_b64, conflict-free
                 *(f32x2*)(aC + i * ACC_ISTR) = dCv;
             }
-            dAp = wave_sum2(dAp);
+            dAp = wave_sum2_dpp(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
             if (np == NP - 1) {
                 // per-item outputs of this chunk (all states folded in): u / delta from the raw vectors loaded at the
@@ -244,8 +255,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     const float xraw = dl[i] + bias;
                     const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
                     const float dyi = dy2[i >> 1][i & 1];
-                    du[i] = dd[i][0] * gBs[i] + dyi * Dv;
-                    ddt[i] = (p0 + i < L) ? (ddt[i] + uu[i] * gBs[i]) * sg : 0.f;
+                    const float gB = gBs2[i][0] + gBs2[i][1];
+                    du[i] = dd[i][0] * gB + dyi * Dv;
+                    ddt[i] = (p0 + i < L) ? (ddt2[i][0] + ddt2[i][1] + uu[i] * gB) * sg : 0.f;
                     dbacc += ddt[i];
                 }
                 if (act) {

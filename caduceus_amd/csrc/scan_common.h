@@ -75,6 +75,16 @@ __device__ __forceinline__ float dot2(f32x2 a, f32x2 b) { return a[0] * b[0] + a
 // neighbouring items into v_pk_* and pays for the transposition with 6 v_mov + 1 v_pk_mov per item pair (12
 // instructions per two items instead of 6; measured in the forward scan's output phase).  -fno-slp-vectorize gives the
 // same instruction count but lets the scheduler hoist the C-tile reads (256 VGPRs + spills instead of 215).
+// acc += a * b as ONE v_pk_fma_f32, pinned by asm (keeps the consumer order of the LDS reads, hence the register
+// pressure, under the programmer's control).  A packed-FMA result needs one wait state before a dependent VALU read:
+// callers produce b one item ahead so that no s_nop is needed.
+__device__ __forceinline__ void pk_fma_acc(f32x2& acc, f32x2 a, f32x2 b) {
+#ifdef CAD_EMU
+    acc = a * b + acc;
+#else
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
+}
 __device__ __forceinline__ float dot2_acc(float acc, f32x2 a, f32x2 b) {
 #ifdef CAD_EMU
     return __builtin_fmaf(a[1], b[1], __builtin_fmaf(a[0], b[0], acc));
@@ -100,6 +110,37 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_row_bcast15(0.f, v);  // lanes 31 / 63: rows 0+1 / rows 2+3
     v += dpp_row_bcast31(0.f, v);  // lane 63: everything
     return cad_readlane(v, 63);
+}
+
+// Two wave-wide sums at once, the two DPP chains interleaved by hand: a DPP read needs two wait states after the VALU
+// write of its source, so one chain alone is padded with an s_nop before every step (and the compiler emits the two
+// chains one after the other); interleaved, each chain's step fills the other's wait states.
+__device__ __forceinline__ f32x2 wave_sum2_dpp(f32x2 v) {
+#ifdef CAD_EMU
+    return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1]));
+#else
+    float x = v[0], y = v[1];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        : "+v"(x), "+v"(y));
+    return f2(cad_readlane(x, 63), cad_readlane(y, 63));
+#endif
 }
 
 // One Kogge-Stone step of the affine-map scan: (A, H) <- (A, H) o (ua, uh) where (ua, uh) is the partner's map

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
         float du[SC_S], dt[SC_S], y[SC_S];
+        f32x2 y2[SC_S];  // per item: the output's even-state / odd-state partial sums (one v_pk_fma per item and pair)
         f32x2 dd[SC_S];  // (dt, dt * u)
 #ifndef SC_FWD_PREFETCH
         if (c > 0) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const float dti = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
-            y[i] = Dv * du[i];
+            y2[i] = f2(Dv * du[i], 0.f);
             dd[i] = f2(dti, dti * du[i]);
         }
         if (a.sum_dt) {  // wave-uniform; only the sequence-parallel / segmented callers ask for it
@@ -172,9 +173,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             if (lane == np) carry = newc;
             cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
 #pragma unroll
-            for (int i = 0; i < SC_S; ++i) {
-                const f32x2 h = ha[i] * h0 + hh[i];
-                y[i] = dot2_acc(y[i], ld2(tC + 2 * i), h);
+            for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
+                const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
+                const f32x4 c4 = *(const f32x4*)(tC + 2 * i);
+                pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
+                pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
             }
             if (more) {
                 sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev);
@@ -182,6 +185,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             }
             if (((tix + 1) & (AHEAD - 1)) == 0) __syncthreads();
         }
+#pragma unroll
+        for (int i = 0; i < SC_S; ++i) y[i] = y2[i][0] + y2[i][1];
         if (z_row) {
             float zz[SC_S];
 #ifndef SC_FWD_PREFETCH
