@@ -28,6 +28,38 @@ def _mentioned(line):
     return out
 
 
+def _walk_to_wait(lines, labels, start, pending, where):
+    """Follows the executed path from line index `start` until the hand-placed `s_waitcnt vmcnt(0)`: conditional branches
+    are not taken (the prefetch and its wait sit under the same wave-uniform conditions, laid out in source order), except
+    `s_cbranch_execnz` (the compiler moved the guarded block out of line: taken = the block runs) and `s_branch`.
+    Every instruction on the way is checked against the in-flight registers."""
+    i, steps, in_asm = start, 0, True
+    while steps < 20000:
+        steps += 1
+        line = lines[i].strip()
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif line.startswith(";;#ASMEND"):
+            in_asm = False
+        elif not line or line.startswith((";", ".")) and not re.match(r"^\.LBB\d+_\d+:", line) or line.endswith(":"):
+            pass
+        elif in_asm and line.startswith("s_waitcnt vmcnt(0)"):
+            return steps
+        elif in_asm and line.startswith("global_load_dword"):
+            assert not (pending & _mentioned(line.split(None, 2)[2])), f"{where}: `{line}` uses an in-flight register as address"
+            pending = pending | _regs(line.split()[1].rstrip(","))  # the second vector of the same prefetch
+        else:
+            assert not line.startswith("s_endpgm"), f"{where}: prefetch still in flight at s_endpgm"
+            hit = pending & _mentioned(line)
+            assert not hit, f"{where}: `{line}` (line {i + 1}) touches in-flight prefetch registers v{sorted(hit)}"
+            m = re.match(r"(s_branch|s_cbranch_execnz)\s+(\.LBB\d+_\d+)", line)
+            if m:
+                i = labels[m.group(2)]
+                continue
+        i += 1
+    raise AssertionError(f"{where}: no s_waitcnt vmcnt(0) found on the path after the prefetch")
+
+
 @pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src", ["scan_fwd.hip", "scan_bwd.hip"])
 def test_async_prefetch_registers_untouched(tmp_path, src):
@@ -36,33 +68,19 @@ def test_async_prefetch_registers_untouched(tmp_path, src):
                            "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "caduceus_amd", "csrc", src)],
                           stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-    kernel, pending, n_loads, n_waits = None, set(), 0, 0
-    i = 0
-    while i < len(lines):
-        line = lines[i].strip()
-        if re.match(r"^_Z\w+:$", line):
-            assert not pending, f"{kernel}: prefetch still in flight at the end of the kernel"
-            kernel = line[:-1]
-        elif line.startswith(";;#ASMSTART"):
-            body = []
-            i += 1
-            while not lines[i].strip().startswith(";;#ASMEND"):
-                body.append(lines[i].strip())
-                i += 1
-            for b in body:
-                if b.startswith("global_load_dword"):
-                    pending |= _regs(b.split()[1].rstrip(","))
-                    n_loads += 1
-                elif b.startswith("s_waitcnt vmcnt(0)"):
-                    pending = set()
-                    n_waits += 1
-                else:
-                    assert not (pending & _mentioned(b)), f"{kernel}: `{b}` touches an in-flight prefetch register"
-        elif line and not line.startswith((";", ".")) and not line.endswith(":"):
-            if line.startswith("s_endpgm"):
-                pending = set()  # early-exit paths (threads that do not stage never wait)
-            else:
-                hit = pending & _mentioned(line)
-                assert not hit, f"{kernel}: `{line}` touches in-flight prefetch registers v{sorted(hit)}"
-        i += 1
+    # split into kernels (labels are local to a function)
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    n_loads = n_waits = 0
+    for k, a in enumerate(starts):
+        b = starts[k + 1] if k + 1 < len(starts) else len(lines)
+        body = lines[a:b]
+        kernel = body[0].split(":")[0]
+        labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        n_waits += sum(1 for i, l in enumerate(body) if l.strip().startswith("s_waitcnt vmcnt(0)")
+                       and body[i - 1].strip().startswith(";;#ASMSTART"))
+        for i, l in enumerate(body):
+            t = l.strip()
+            if t.startswith("global_load_dword") and body[i - 1].strip().startswith(";;#ASMSTART"):
+                n_loads += 1
+                _walk_to_wait(body, labels, i + 1, _regs(t.split()[1].rstrip(",")), f"{kernel} line {i + 1}")
     assert n_loads >= 8 and n_waits >= 4, (n_loads, n_waits)  # every VEC instantiation contains the pattern
