@@ -118,8 +118,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     for (int64_t c = nchunks - 1; c >= 0; --c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
-        float ddt[SC_S];
-        f32x2 ddt2[SC_S], gBs2[SC_S];  // sums over the states of g * h_{i-1} * a * A and of <g, B>, even / odd states apart
+        float ddt[SC_S], gBs[SC_S];   // sum over the states of g * h_{i-1} * a * A  and of  <g, B>
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
@@ -148,8 +147,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const bool ok = p0 + i < L;
                 const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
-                ddt2[i] = f2(0.f);
-                gBs2[i] = f2(0.f);
+                ddt[i] = 0.f;
+                gBs[i] = 0.f;
                 dDacc += dyi * uu[i];
                 dd[i] = f2(dti, dti * uu[i]);
                 sum_dt += dti;
@@ -234,8 +233,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
-                pk_fma_acc(ddt2[i], t, Av);
-                pk_fma_acc(gBs2[i], g, Bv);
+                ddt[i] = dot2_acc(ddt[i], t, Av);  // scalar accumulators: the packed form (one v_pk_fma each) needs 16 more
+                gBs[i] = dot2_acc(gBs[i], g, Bv);  // VGPRs, spills, and the spill traffic reaches HBM (+0.75 GB per launch)
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * SC_DY(i);
@@ -255,9 +254,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     const float xraw = dl[i] + bias;
                     const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
                     const float dyi = dy2[i >> 1][i & 1];
-                    const float gB = gBs2[i][0] + gBs2[i][1];
-                    du[i] = dd[i][0] * gB + dyi * Dv;
-                    ddt[i] = (p0 + i < L) ? (ddt2[i][0] + ddt2[i][1] + uu[i] * gB) * sg : 0.f;
+                    du[i] = dd[i][0] * gBs[i] + dyi * Dv;
+                    ddt[i] = (p0 + i < L) ? (ddt[i] + uu[i] * gBs[i]) * sg : 0.f;
                     dbacc += ddt[i];
                 }
                 if (act) {
