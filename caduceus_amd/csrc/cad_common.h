@@ -34,6 +34,7 @@
 // ---- small numeric helpers ---------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((vector_size(8)));  // maps to v_pk_{mul,fma,add}_f32 on gfx950
 typedef float f32x4 __attribute__((vector_size(16)));
+typedef uint32_t u32x2 __attribute__((vector_size(8)));
 
 struct bf16_t {
     uint16_t v;

@@ -32,6 +32,17 @@ struct ScanBwdSets {
                                         // (items i and i + 4 of neighbouring lanes) fall into different LDS banks
 #define ACC_TILE (SC_S * ACC_ISTR)      // floats per (wave, tensor) region, layout [item i][lane j][state s]
 #define ACC_BUF (SC_W * 2 * ACC_TILE)  // floats per buffer: [wave][dB,dC][ACC_TILE]
+// bf16 kernels (8-wave workgroups) keep the slab as packed bf16x2 dwords -- one dword = both states of one position --
+// laid out [item pair][lane][2 items]: half the LDS bytes in both directions (8 ds_write_b64 instead of 16 per lane and
+// pair-step; the flush reads 8 ds_read_b64 at 256 B/clk instead of 16 ds_read2_b32 at 128 B/clk).  The contributions are
+// rounded to bf16 before the 8-channel sum; the partial slots they are summed into are bf16 anyway (same error order).
+#ifndef SC_SLAB_PACKED
+#define SC_SLAB_PACKED 1
+#endif
+#define PK_IPS (64 * 2 + 16)            // dwords between item pairs: 128 + 16 pad -> the flush's ds_read_b64 (lanes j..j+7 of
+                                        // the four item pairs per half-wave) and the ds_write_b64 are bank-conflict-free
+#define PK_TILE ((SC_S / 2) * PK_IPS)   // dwords per (wave, tensor) region
+#define PK_BUF (SC_W * 2 * PK_TILE)     // dwords per buffer
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
 #endif
@@ -47,6 +58,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     const cad_scan_bwd_args& a = sets.s[blockIdx.z];
     float* acc = smem + 4 * TILE;
+    constexpr bool PACKED = SC_SLAB_PACKED && sizeof(T) == 2 && SC_W == 8 && SC_SLAB_BUFS == 2;
+    uint32_t* accp = (uint32_t*)acc;
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
     const int64_t sb = blockIdx.y;
@@ -226,6 +239,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (lane == np) carryG = newc;
             // 3. gradients
             f32x2 dAp = f2(0.f);
+            uint32_t pkB = 0, pkC = 0;
 #pragma unroll
             for (int i = SC_S - 1; i >= 0; --i) {
                 const f32x2 Bv = Bw[i];
@@ -238,8 +252,19 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * SC_DY(i);
-                *(f32x2*)(aB + i * ACC_ISTR) = dBv;  // ds_write_b64, conflict-free
-                *(f32x2*)(aC + i * ACC_ISTR) = dCv;
+                if constexpr (PACKED) {
+                    const uint32_t pB = cad_pack_bf16x2(dBv[0], dBv[1]), pC = cad_pack_bf16x2(dCv[0], dCv[1]);
+                    if (i & 1) {
+                        pkB = pB, pkC = pC;  // the odd item waits for its even partner: one 8-byte store per item pair
+                    } else {
+                        uint32_t* qB = accp + buf * PK_BUF + wave * 2 * PK_TILE + (i >> 1) * PK_IPS + lane * 2;
+                        *(u32x2*)qB = u32x2{pB, pkB};
+                        *(u32x2*)(qB + PK_TILE) = u32x2{pC, pkC};
+                    }
+                } else {
+                    *(f32x2*)(aB + i * ACC_ISTR) = dBv;  // ds_write_b64, conflict-free
+                    *(f32x2*)(aC + i * ACC_ISTR) = dCv;
+                }
             }
             dAp = wave_sum2_dpp(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
@@ -278,7 +303,39 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // sum the SC_W regions and flush: thread t owns one tensor (dB / dC), one state of the pair and FT
             // consecutive positions, stored 4 at a time (8/16-byte stores).  With two slab buffers the next pair writes
             // the other buffer, so one barrier per pair suffices.
-            {
+            if constexpr (PACKED) {
+                // thread t owns one tensor and the positions (lane j, items 2ip, 2ip + 1): 8 ds_read_b64 (one per channel),
+                // each {item 2ip: states 0|1, item 2ip + 1: states 0|1}; two 4-byte stores (one per state row)
+                const int t = threadIdx.x;
+                const int ten = t >> 8, j = (t & 255) >> 2, ip = t & 3;
+                const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + ip * PK_IPS + j * 2;
+                float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;  // s<item><state>
+#pragma unroll
+                for (int w = 0; w < SC_W; ++w) {
+                    const u32x2 v = *(const u32x2*)(src + w * 2 * PK_TILE);
+                    s00 += cad_bits2f(v[0] << 16), s01 += cad_bits2f(v[0] & 0xFFFF0000u);
+                    s10 += cad_bits2f(v[1] << 16), s11 += cad_bits2f(v[1] & 0xFFFF0000u);
+                }
+                const int64_t p = base + j * SC_S + 2 * ip;
+                T* grow = (ten ? dCg : dBg) + ((int64_t)n0 * SB + sb) * L;
+                const int64_t srow = SB * L;  // next state's row
+                if (VEC) {
+                    if (p < L) {
+                        const int64_t q = rev ? (L - p - 2) : p;
+                        *(uint32_t*)(grow + q) = rev ? cad_pack_bf16x2(s10, s00) : cad_pack_bf16x2(s00, s10);
+                        if (n0 + 1 < N) *(uint32_t*)(grow + srow + q) = rev ? cad_pack_bf16x2(s11, s01) : cad_pack_bf16x2(s01, s11);
+                    }
+                } else {
+                    if (p < L) {
+                        grow[cad_phys(p, L, rev)] = from_f32<T>(s00);
+                        if (n0 + 1 < N) grow[srow + cad_phys(p, L, rev)] = from_f32<T>(s01);
+                    }
+                    if (p + 1 < L) {
+                        grow[cad_phys(p + 1, L, rev)] = from_f32<T>(s10);
+                        if (n0 + 1 < N) grow[srow + cad_phys(p + 1, L, rev)] = from_f32<T>(s11);
+                    }
+                }
+            } else {
                 constexpr int QT = 64 * SC_W / 4;     // threads per (tensor, state)
                 constexpr int FT = SC_CHUNK / QT;     // positions per thread (4 or 8)
                 const int t = threadIdx.x;
@@ -408,7 +465,8 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
                       16) == 0;
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + SC_SLAB_BUFS * ACC_BUF) * sizeof(float);
+    const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
+    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) * sizeof(float);
     if (a->dtype == CAD_F32) {
         if (vec)
             CAD_LAUNCH((scan_bwd_kernel<float, true>), grid, block, shmem, stream, ks);
