@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             sc_stage_seek<T, SC_S>(sctx, base, L, rev);
             sc_stage_issue<T, SC_S>(st, sctx, 0, N);
         } else {
-            sc_stage_load<T, SC_S, VEC>(st, sctx, 0, N, base, L, rev);
+            sc_stage_load<T, SC_S, false>(st, sctx, 0, N, base, L, rev);
         }
         sc_load_raw<T, SC_S, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
         sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     if (nn == 0) sc_stage_seek<T, SC_S>(sctx, nb, L, rev);  // wave-uniform: once per chunk
                     sc_stage_issue<T, SC_S>(st, sctx, nn, N);
                 } else {
-                    sc_stage_load<T, SC_S, VEC>(st, sctx, nn, N, nb, L, rev);
+                    sc_stage_load<T, SC_S, false>(st, sctx, nn, N, nb, L, rev);
                 }
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;

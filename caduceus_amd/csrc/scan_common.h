@@ -408,33 +408,27 @@ __device__ __forceinline__ void sc_stage_issue(StageRegs<T, SC_SV(S)>& r, const 
     r.ok1 = c.in && two;
 }
 
+// Element-wise staging load (ragged L or unaligned rows; the vector path is sc_stage_seek + sc_stage_issue).
 template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const StageCtx<T>& c, int n0, int N, int64_t base,
                                               int64_t L, int rev) {
+    static_assert(!VEC, "the vector path stages through sc_stage_seek / sc_stage_issue");
     constexpr int SV = SC_SV(S);
     if (!c.on) return;
     const int64_t p0 = base + c.tok;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         StVec<T, SV>& dst = s ? r.s1 : r.s0;
-        if constexpr (VEC) {
-            const bool ok = n0 + s < N && p0 < L;
-            const int ns = (n0 + s < N) ? n0 + s : n0;  // n0 < N always
-            const int64_t l0 = (p0 < L) ? (rev ? (L - p0 - SV) : p0) : 0;
-            sc_async_load(dst, c.src + ns * c.row_stride + l0);
-            (s ? r.ok1 : r.ok0) = ok;
-        } else {
-            const T* row = c.src + (int64_t)(n0 + s) * c.row_stride;
-            (s ? r.ok1 : r.ok0) = true;
+        const T* row = c.src + (int64_t)(n0 + s) * c.row_stride;
+        (s ? r.ok1 : r.ok0) = true;
 #pragma unroll
-            for (int j = 0; j < SV; ++j) {
-                const int64_t p = p0 + j;
-                const int k = rev ? (SV - 1 - j) : j;
-                if (n0 + s < N && p < L)
-                    dst.v[k] = row[cad_phys(p, L, rev)];
-                else
-                    dst.v[k] = from_f32<T>(0.f);
-            }
+        for (int j = 0; j < SV; ++j) {
+            const int64_t p = p0 + j;
+            const int k = rev ? (SV - 1 - j) : j;
+            if (n0 + s < N && p < L)
+                dst.v[k] = row[cad_phys(p, L, rev)];
+            else
+                dst.v[k] = from_f32<T>(0.f);
         }
     }
 }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         if constexpr (VEC)                                                             \
             sc_stage_issue<T, SC_S>(st, sctx, 2 * s_np, N);                            \
         else                                                                           \
-            sc_stage_load<T, SC_S, VEC>(st, sctx, 2 * s_np, N, s_base, L, rev);        \
+            sc_stage_load<T, SC_S, false>(st, sctx, 2 * s_np, N, s_base, L, rev);        \
     } while (0)
 #define SC_FWD_ADVANCE()                                                               \
     do {                                                                               \
