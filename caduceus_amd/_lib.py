@@ -70,7 +70,7 @@ class ScanBwdArgs(C.Structure):
                 ("delta_bias", _p), ("dout", _p), ("out", _p), ("chunk_state", _p), ("du", _p), ("ddelta", _p), ("dz", _p),
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
-                ("n_partials", _i), ("dhT", _p), ("dh0", _p)]
+                ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p)]
 
 
 class ScanTmArgs(C.Structure):

@@ -74,10 +74,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const T* d_row = (const T*)a.delta + row_off;
     const T* z_row = a.z ? (const T*)a.z + row_off : nullptr;
     const T* g_row = (const T*)a.dout + row_off;
-    const T* o_row = a.out ? (const T*)a.out + row_off : nullptr;
+    T* dz_row = a.dz ? (T*)a.dz + row_off : nullptr;
+    const T* o_row = (a.out && dz_row) ? (const T*)a.out + row_off : nullptr;      // only the gate gradient needs it
+    const T* o2_row = (a.out2 && dz_row) ? (const T*)a.out2 + row_off : nullptr;  // the other scan under the same gate
     T* du_row = (T*)a.du + row_off;
     T* dd_row = (T*)a.ddelta + row_off;
-    T* dz_row = a.dz ? (T*)a.dz + row_off : nullptr;
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
     const float Dv = a.D ? a.D[e] : 0.f;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 
     StageRegs<T, SC_SV(SC_S)> st;
     StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
-    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw;  // u_raw / d_raw stay in registers until the chunk's epilogue
+    ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw, o2_raw;  // u_raw / d_raw stay in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
         if constexpr (VEC) {
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
         sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
         if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
-        if (z_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
+        if (o_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
+        if (o2_row) sc_load_raw<T, SC_S, VEC>(o2_row, base + (int64_t)lane * SC_S, L, rev, o2_raw);
         sc_stage_store<T, SC_S, VEC>(st, smem, rev);
     }
     __syncthreads();
@@ -145,15 +147,25 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 // out = y * z * sigmoid(z)  =>  y * sigmoid(z) = out / z ;  dz = dout * y * sigmoid(z) * (1 + z (1 - sigmoid(z)))
                 float zz[SC_S], oo[SC_S], dzv[SC_S];
                 sc_unpack<T, SC_S>(z_raw, rev, zz);
-                sc_unpack<T, SC_S>(o_raw, rev, oo);
+                if (o_row) {  // wave-uniform: this set writes the gate gradient
+                    sc_unpack<T, SC_S>(o_raw, rev, oo);
+                    if (o2_row) {  // ... of both scans sharing the gate
+                        float o2[SC_S];
+                        sc_unpack<T, SC_S>(o2_raw, rev, o2);
+#pragma unroll
+                        for (int i = 0; i < SC_S; ++i) oo[i] += o2[i];
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < SC_S; ++i) {
                     const float sg = cad_sigmoid(zz[i]);
-                    const float ys = (zz[i] == 0.f) ? 0.f : oo[i] * cad_rcp(zz[i]);
-                    dzv[i] = dy[i] * ys * (1.f + zz[i] * (1.f - sg));
+                    if (o_row) {
+                        const float ys = (zz[i] == 0.f) ? 0.f : oo[i] * cad_rcp(zz[i]);
+                        dzv[i] = dy[i] * ys * (1.f + zz[i] * (1.f - sg));
+                    }
                     dy[i] *= zz[i] * sg;
                 }
-                if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
+                if (o_row && act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
             }
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
@@ -298,7 +310,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 sc_load_raw<T, SC_S, VEC>(d_row, pn, L, rev, d_raw);
                 sc_load_raw<T, SC_S, VEC>(g_row, pn, L, rev, g_raw);
                 if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, pn, L, rev, z_raw);
-                if (z_row) sc_load_raw<T, SC_S, VEC>(o_row, pn, L, rev, o_raw);
+                if (o_row) sc_load_raw<T, SC_S, VEC>(o_row, pn, L, rev, o_raw);
+                if (o2_row) sc_load_raw<T, SC_S, VEC>(o2_row, pn, L, rev, o2_raw);
             }
             // sum the SC_W regions and flush: thread t owns one tensor (dB / dC), one state of the pair and FT
             // consecutive positions, stored 4 at a time (8/16-byte stores).  With two slab buffers the next pair writes
@@ -446,8 +459,9 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
         const cad_scan_bwd_args* a = &sets[i];
         CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && a->dout && a->chunk_state);
         CAD_CHECK_ARG(a->du && a->ddelta && a->dA && a->dB && a->dC);
-        CAD_CHECK_ARG((a->z == nullptr) == (a->dz == nullptr));
-        CAD_CHECK_ARG(a->z == nullptr || a->out != nullptr);
+        CAD_CHECK_ARG(a->z != nullptr || a->dz == nullptr);               // dz needs the gate; dz == NULL: not wanted here
+        CAD_CHECK_ARG(a->dz == nullptr || a->out != nullptr);
+        CAD_CHECK_ARG(a->out2 == nullptr || a->dz != nullptr);
         CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
         CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
         CAD_CHECK_ARG(a->n_partials == cad_scan_bwd_partials(a->E));
@@ -460,7 +474,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     bool vec = (a->L % SC_S) == 0;
     for (int i = 0; i < nsets; ++i)
         vec = vec && (((uintptr_t)sets[i].u | (uintptr_t)sets[i].delta | (uintptr_t)sets[i].z | (uintptr_t)sets[i].dout | (uintptr_t)sets[i].out |
-                       (uintptr_t)sets[i].du | (uintptr_t)sets[i].ddelta | (uintptr_t)sets[i].dz |
+                       (uintptr_t)sets[i].du | (uintptr_t)sets[i].ddelta | (uintptr_t)sets[i].dz | (uintptr_t)sets[i].out2 |
                        (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm | (uintptr_t)sets[i].dB | (uintptr_t)sets[i].dC) %
                       16) == 0;
     CadProfScope prof(1, stream);

@@ -15,6 +15,7 @@ All kernels are the C-ABI entry points of include/caduceus_hip.h; GEMMs are hipB
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -82,6 +83,11 @@ def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
         return torch.mm(a_cm, b_tm).float()
     Kc = T // n
     return torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_tm.view(n, Kc, -1)).float().sum(0)
+
+
+# The two scans of a BiMamba layer share the gate z and the upstream gradient: set 0's backward kernel evaluates the gate
+# gradient of both (cad_scan_bwd_args.out2).  CADUCEUS_AMD_SHARED_GATE=0 keeps one dz per set + an add (A/B switch).
+_SHARED_GATE = os.environ.get("CADUCEUS_AMD_SHARED_GATE", "1") != "0"
 
 
 class BiMambaMixerFn(torch.autograd.Function):
@@ -161,8 +167,7 @@ class BiMambaMixerFn(torch.autograd.Function):
         y_f, y_r = ycat[:E], ycat[E:]
         dW_cat = _wgrad_cm_tm(ycat.view(2 * E, T), dout2d)  # (2E, D): both halves multiply the same tied weight
         dW_out = (dW_cat[:E] + dW_cat[E:]).t()
-        dxz = torch.empty_like(xz)       # [dx ; dz_f + dz_r]
-        dz_r = torch.empty_like(z)
+        dxz = torch.empty_like(xz)       # [dx ; dz]: the gate z is shared, set 0's kernel writes the gradient of both gates
         sets = [rest[12 * i:12 * i + 12] for i in range(2)]
         args = (L.ScanBwdArgs * 2)()
         work = []
@@ -171,7 +176,8 @@ class BiMambaMixerFn(torch.autograd.Function):
             N = A.shape[1]
             R = dbc.shape[0] - 2 * N
             du, ddelta = torch.empty_like(xc), torch.empty_like(xc)
-            dz = dxz[E:] if i == 0 else dz_r
+            dz = dxz[E:] if i == 0 else (None if _SHARED_GATE else torch.empty_like(z))
+            dz_r = dz if i == 1 else None
             dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Df), torch.zeros_like(bfz)
             npart = lib.cad_scan_bwd_partials(E)
             dBC = torch.empty((2, npart, N, SB, Lq), dtype=act, device=xc.device)
@@ -181,7 +187,8 @@ class BiMambaMixerFn(torch.autograd.Function):
                                     L.ptr(bfz), L.ptr(dy), L.ptr(y_f if i == 0 else y_r), L.ptr(state), L.ptr(du),
                                     L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
                                     L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
-                                    dirs[i][0], dirs[i][1], L.dtype_code(act), npart)
+                                    dirs[i][0], dirs[i][1], L.dtype_code(act), npart, None, None,
+                                    L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None)
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
         L.check(lib.cad_scan_bwd_multi(args, 2, stream), "cad_scan_bwd_multi")
         grads, dxcs, part = [], [], []
@@ -210,7 +217,8 @@ class BiMambaMixerFn(torch.autograd.Function):
             grads += [dwc.reshape(meta[0][1]).to(meta[0][0]), None if dbc_conv is None else dbc_conv.to(meta[1][0]),
                       dW_x.to(meta[2][0]), dW_dt.to(meta[3][0]), dbias.to(meta[4][0]), dA_log.to(meta[5][0]),
                       dD.to(meta[6][0])]
-        dxz[E:].add_(dz_r)  # the two parameter sets share the gate z
+        if dz_r is not None:
+            dxz[E:].add_(dz_r)
         dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
         dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
         return (dx2d, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)

@@ -211,7 +211,10 @@ int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
  * k; cad_reduce_partials folds the slots (fp32 accumulation) into the final (N,SB,L) gradient.
  * chunk_state: as written by the forward.  out: the forward's (gated) output, required when z != NULL: the gate gradient
  * uses y = out / silu(z) instead of re-accumulating y (dz is 0 where z == 0 exactly).
- * Optional carries (E, SB, N) fp32: dhT = gradient w.r.t. the forward's hT (default 0), dh0 = gradient w.r.t. h0 (written). */
+ * Optional carries (E, SB, N) fp32: dhT = gradient w.r.t. the forward's hT (default 0), dh0 = gradient w.r.t. h0 (written).
+ * Shared gate (BiMamba: the forward and the reverse scan are gated by the same z and receive the same dout): pass the
+ * other scan's gated output as out2 and dz receives the gate gradient of BOTH scans (one fp32 evaluation, one rounding);
+ * the other parameter set of the launch then passes dz = NULL (z is still required there: it gates dout). */
 typedef struct {
     const void* u;
     const void* delta;
@@ -239,6 +242,7 @@ typedef struct {
     int n_partials;
     const float* dhT;
     float* dh0;
+    const void* out2;
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
