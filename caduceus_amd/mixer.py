@@ -38,15 +38,30 @@ def _conv_fwd2(x, params, split, dirs):
     return outs
 
 
-def _conv_bwd2(x, params, douts, dx, split, dirs):
-    """dx = sum over both parameter sets of their input gradients (written once), dw / dbias per set."""
+def _zeros_f32(shapes, device):
+    """fp32 zero tensors of the given shapes carved out of ONE allocation (one fill kernel instead of one per tensor:
+    the accumulated per-channel gradients of a layer are ten tiny tensors)."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + (n + 3) // 4 * 4)  # 16-byte aligned views
+    flat = torch.zeros((offs[-1],), dtype=torch.float32, device=device)
+    return [flat[o:o + n].view(s) for o, n, s in zip(offs, sizes, shapes)]
+
+
+def _conv_bwd2(x, params, douts, dx, split, dirs, bufs=None):
+    """dx = sum over both parameter sets of their input gradients (written once), dw / dbias per set.
+    bufs: optional pre-zeroed fp32 (dw, db) per set."""
     E, SB, Lq = x.shape
     n = len(params)
     args = (L.Conv1dBwdArgs * n)()
     res = []
     for i, (wf, bf) in enumerate(params):
-        dw = torch.zeros_like(wf)
-        db = None if bf is None else torch.zeros_like(bf)
+        if bufs is not None:
+            dw, db = bufs[i]
+        else:
+            dw = torch.zeros_like(wf)
+            db = None if bf is None else torch.zeros_like(bf)
         stream = L.stream_and_check(x, wf, bf, douts[i], dx, dw, db)
         args[i] = L.Conv1dBwdArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(douts[i]), L.ptr(dx), L.ptr(dw), L.ptr(db), SB, Lq,
                                   split, E, wf.shape[1], dirs[i][0], dirs[i][1], L.dtype_code(x.dtype), 0)
@@ -171,6 +186,11 @@ class BiMambaMixerFn(torch.autograd.Function):
         sets = [rest[12 * i:12 * i + 12] for i in range(2)]
         args = (L.ScanBwdArgs * 2)()
         work = []
+        zshapes = []
+        for i in range(2):  # per set: dA, dD, ddelta_bias (scan), dw, db (conv): accumulated by the kernels -> zeroed
+            _, _, A_, _, Df_, bfz_, wf_, bf_ = sets[i][:8]
+            zshapes += [A_.shape, Df_.shape, bfz_.shape, wf_.shape, (bf_.shape if bf_ is not None else (0,))]
+        zbuf = _zeros_f32(zshapes, x2d.device)
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
             N = A.shape[1]
@@ -178,7 +198,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             du, ddelta = torch.empty_like(xc), torch.empty_like(xc)
             dz = dxz[E:] if i == 0 else (None if _SHARED_GATE else torch.empty_like(z))
             dz_r = dz if i == 1 else None
-            dA, dD, dbias = torch.zeros_like(A), torch.zeros_like(Df), torch.zeros_like(bfz)
+            dA, dD, dbias = zbuf[5 * i:5 * i + 3]
             npart = lib.cad_scan_bwd_partials(E)
             dBC = torch.empty((2, npart, N, SB, Lq), dtype=act, device=xc.device)
             Bm, Cm = dbc[R:R + N], dbc[R + N:]
@@ -210,7 +230,8 @@ class BiMambaMixerFn(torch.autograd.Function):
             du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))  # in place: no copy of the 268 MB addend
             dxcs.append(du)
             part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
-        conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs)
+        conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs,
+                            bufs=[(zbuf[5 * i + 3], zbuf[5 * i + 4] if sets[i][7] is not None else None) for i in range(2)])
         for i in range(2):
             meta = pmeta[i]
             (dwc, dbc_conv), (dW_x, dW_dt, dbias, dA_log, dD) = conv_g[i], part[i]
