@@ -70,7 +70,8 @@ class ScanBwdArgs(C.Structure):
                 ("delta_bias", _p), ("dout", _p), ("out", _p), ("chunk_state", _p), ("du", _p), ("ddelta", _p), ("dz", _p),
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
-                ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p)]
+                ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p), ("gate_fix_list", _p), ("gate_fix_count", _p),
+                ("gate_fix_dz", _p)]
 
 
 class ScanTmArgs(C.Structure):
@@ -89,7 +90,7 @@ class MlmArgs(C.Structure):
 class LmHeadArgs(C.Structure):
     _fields_ = [("hidden", _p), ("weight", _p), ("comp", _p), ("labels", _p), ("logits", _p), ("loss_sum", _p),
                 ("count", _p), ("rows", _i64), ("D", _i), ("V", _i), ("n_strands", _i), ("ignore_index", _i64),
-                ("dtype", _i)]
+                ("dtype", _i), ("block_partials", _p)]
 
 
 # every exported symbol of include/caduceus_hip.h: name -> (restype, argtypes)
@@ -113,12 +114,15 @@ SYMBOLS = {
     "cad_scan_bwd_multi": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_reduce_partials": (_i, [_p, _i, _i64, _p, _i, _p]),
     "cad_scan_bwd_partials": (_i, [_i]),
+    "cad_scan_bwd_gate_fix": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
+    "cad_scan_gate_fix_entries": (_i64, [_i, _i64, _i64]),
     "cad_scan_tm_fwd": (_i, [C.POINTER(ScanTmArgs), _p]),
     "cad_scan_tm_fwd_multi": (_i, [C.POINTER(ScanTmArgs), _i, _p]),
     "cad_scan_tm_block_len": (_i64, []),
     "cad_scan_tm_state_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_scan_tm_scratch_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
+    "cad_lm_head_partials": (_i64, [_i64]),
     "cad_tokenize_mlm": (_i, [C.POINTER(MlmArgs), _p]),
     "cad_mlm_threshold": (C.c_uint32, [C.c_double]),
     "cad_hg38_interval": (_i, [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),

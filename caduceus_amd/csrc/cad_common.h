@@ -222,6 +222,72 @@ __device__ __forceinline__ float cad_readlane(float v, int l) {
 __device__ __forceinline__ int cad_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// ---- matrix core (MFMA) ------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16:  D (16 x 16 fp32) = A (16 x 32 bf16) * B (32 x 16 bf16) + C, one tile per wave.
+// Operand layouts (lane l, g = l >> 4):  A: row i = l & 15, elements k = 8g .. 8g+7 (4 dwords, element t in dword t >> 1,
+// half t & 1);  B: column j = l & 15, elements k = 8g .. 8g+7;  C / D: column j = l & 15, rows 4g + r (r = 0..3).
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+#ifdef CAD_EMU
+__device__ __forceinline__ f32x4 cad_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    const int lane = emu::lane_id();
+    const int col = lane & 15, rg = lane >> 4;
+    float bk[32];      // B[k][col]
+    float ak[4][32];   // A[4 rg + r][k]
+    for (int g = 0; g < 4; ++g) {
+        for (int h = 0; h < 2; ++h) {
+            const uint64_t mine_b = (uint64_t)b[2 * h] | ((uint64_t)b[2 * h + 1] << 32);
+            const uint64_t vb = emu_exchange(mine_b, g * 16 + col);
+            for (int t = 0; t < 4; ++t)
+                bk[8 * g + 4 * h + t] = cad_bits2f((uint32_t)((vb >> (16 * t)) & 0xffffu) << 16);
+            const uint64_t mine_a = (uint64_t)a[2 * h] | ((uint64_t)a[2 * h + 1] << 32);
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t va = emu_exchange(mine_a, g * 16 + 4 * rg + r);
+                for (int t = 0; t < 4; ++t)
+                    ak[r][8 * g + 4 * h + t] = cad_bits2f((uint32_t)((va >> (16 * t)) & 0xffffu) << 16);
+            }
+        }
+    }
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        float s = c[r];
+        for (int k = 0; k < 32; ++k) s += ak[r][k] * bk[k];
+        d[r] = s;
+    }
+    return d;
+}
+#else
+__device__ __forceinline__ f32x4 cad_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+    typedef float f32x4_hw __attribute__((ext_vector_type(4)));
+    const f32x4_hw r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b),
+                                                               __builtin_bit_cast(f32x4_hw, c), 0, 0, 0);
+    return __builtin_bit_cast(f32x4, r);
+}
+#endif
+// two fp32 -> packed bf16x2 through a conversion the COMPILER sees (it emits v_cvt_pk_bf16_f32 and pads the MFMA / DOT
+// result hazards itself; the inline-asm cad_pack_bf16x2 is invisible to its hazard recognizer)
+__device__ __forceinline__ uint32_t cad_pack_bf16x2_safe(float lo, float hi) {
+#ifdef CAD_EMU
+    return cad_pack_bf16x2(lo, hi);
+#else
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+    const f32x2_hw v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+#endif
+}
+
+// wave-uniform "any lane" vote
+__device__ __forceinline__ bool cad_wave_any(bool p) {
+#ifdef CAD_EMU
+    bool r = false;
+    for (int l = 0; l < emu::wave_lanes(); ++l) r = emu_exchange((int)p, l) != 0 || r;
+    return r;
+#else
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#endif
+}
+
 // compiler-only fence: keeps the scheduler from hoisting (LDS) loads across this point, which bounds live ranges
 __device__ __forceinline__ void cad_sched_fence() {
 #ifndef CAD_EMU

@@ -85,7 +85,10 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_fwd_kernel(cad_lm_head_
                 l += red[w][0];
                 n += red[w][1];
             }
-            if (n > 0.f) {
+            if (a.block_partials) {  // deterministic: one slot per workgroup, folded in a fixed order by lm_loss_fold_kernel
+                a.block_partials[2 * blockIdx.x] = l;
+                a.block_partials[2 * blockIdx.x + 1] = n;
+            } else if (n > 0.f) {
                 atomicAdd(a.loss_sum, l);
                 atomicAdd(a.count, n);
             }
@@ -93,7 +96,41 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_fwd_kernel(cad_lm_head_
     }
 }
 
+// second stage of the deterministic loss: one workgroup folds the per-workgroup (loss, count) pairs with a fixed-shape
+// tree (the same association order on every run and for every grid of the same size)
+#define LM_FOLD_THREADS 256
+__global__ __launch_bounds__(LM_FOLD_THREADS) void lm_loss_fold_kernel(const float* parts, int nparts, float* loss_sum,
+                                                                       float* count) {
+    __shared__ float sl[LM_FOLD_THREADS], sn[LM_FOLD_THREADS];
+    float l = 0.f, n = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += LM_FOLD_THREADS) {
+        l += parts[2 * i];
+        n += parts[2 * i + 1];
+    }
+    sl[threadIdx.x] = l;
+    sn[threadIdx.x] = n;
+    __syncthreads();
+    for (int st = LM_FOLD_THREADS / 2; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            sl[threadIdx.x] += sl[threadIdx.x + st];
+            sn[threadIdx.x] += sn[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_sum[0] += sl[0];
+        count[0] += sn[0];
+    }
+}
+
 }  // namespace
+
+static int64_t lm_head_blocks(int64_t rows) {
+    int64_t nb = (rows + LM_WAVES - 1) / LM_WAVES;
+    return nb > 4096 ? 4096 : nb;
+}
+
+extern "C" int64_t cad_lm_head_partials(int64_t rows) { return 2 * lm_head_blocks(rows); }
 
 extern "C" int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream) {
     CAD_CHECK_ARG(a && a->hidden && a->weight && a->logits);
@@ -102,8 +139,7 @@ extern "C" int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream) {
     CAD_CHECK_ARG(!a->labels || (a->loss_sum && a->count));
     if (a->V > LM_VMAX) return CAD_ERR_UNSUPPORTED;
     CadProfScope prof(7, stream);
-    int64_t nb = (a->rows + LM_WAVES - 1) / LM_WAVES;
-    if (nb > 4096) nb = 4096;
+    const int64_t nb = lm_head_blocks(a->rows);
     dim3 grid((unsigned)nb), block(64 * LM_WAVES);
     if (a->dtype == CAD_F32)
         CAD_LAUNCH((lm_head_fwd_kernel<float>), grid, block, 0, stream, *a);
@@ -111,5 +147,8 @@ extern "C" int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream) {
         CAD_LAUNCH((lm_head_fwd_kernel<bf16_t>), grid, block, 0, stream, *a);
     else
         return CAD_ERR_UNSUPPORTED;
+    if (a->labels && a->block_partials)
+        CAD_LAUNCH(lm_loss_fold_kernel, dim3(1), dim3(LM_FOLD_THREADS), 0, stream, (const float*)a->block_partials, (int)nb,
+                   a->loss_sum, a->count);
     return cad_after_launch();
 }

@@ -32,16 +32,22 @@ struct ScanBwdSets {
                                         // (items i and i + 4 of neighbouring lanes) fall into different LDS banks
 #define ACC_TILE (SC_S * ACC_ISTR)      // floats per (wave, tensor) region, layout [item i][lane j][state s]
 #define ACC_BUF (SC_W * 2 * ACC_TILE)  // floats per buffer: [wave][dB,dC][ACC_TILE]
-// bf16 kernels (8-wave workgroups) keep the slab as packed bf16x2 dwords -- one dword = both states of one position --
-// laid out [item pair][lane][2 items]: half the LDS bytes in both directions (8 ds_write_b64 instead of 16 per lane and
-// pair-step; the flush reads 8 ds_read_b64 at 256 B/clk instead of 16 ds_read2_b32 at 128 B/clk).  The contributions are
-// rounded to bf16 before the 8-channel sum; the partial slots they are summed into are bf16 anyway (same error order).
+// bf16 kernels (8-wave workgroups) keep the slab as packed bf16x2 dwords -- one dword = both states of one position.
+// Region of one (channel = wave, tensor): [q = item-pair block 0/1][lane 64][4 dwords = items 4q .. 4q+3], i.e. a lane's
+// four items of block q form one 16-byte PIECE.  The contributions are rounded to bf16 before the 8-channel sum; the
+// partial slots they are summed into are bf16 anyway (same error order).
+// The sum over the 8 channels runs on the MATRIX core: for a tile of 16 pieces, lane (g, j) feeds piece j of channel g
+// (then g + 4) as the B operand of v_mfma_f32_16x16x32_bf16, the A operand is a constant 0/1 selection matrix
+// A[i][8g + t] = (t == pi(i & 7)), so  D[i][j] = sum over the channels of element pi(i) of piece j  in fp32.  pi orders
+// the rows as (state 0: items 0..3, state 1: items 0..3), which leaves every D lane with four consecutive positions of
+// one state row.  One wave owns the two tiles (q = 0, 1) of (tensor, 16-lane block): 4 ds_read_b128 + 4 MFMA + 4
+// v_cvt_pk + one 16-byte store per pair-step instead of 8 ds_read_b64 + ~64 VALU + 2 stores per thread.
 #ifndef SC_SLAB_PACKED
 #define SC_SLAB_PACKED 1
 #endif
-#define PK_IPS (64 * 2 + 16)            // dwords between item pairs: 128 + 16 pad -> the flush's ds_read_b64 (lanes j..j+7 of
-                                        // the four item pairs per half-wave) and the ds_write_b64 are bank-conflict-free
-#define PK_TILE ((SC_S / 2) * PK_IPS)   // dwords per (wave, tensor) region
+#define PK_Q (64 * 4)                   // dwords per item-pair block
+#define PK_TILE (2 * PK_Q)              // dwords per (wave, tensor) region (2 KB: a multiple of the 256-byte bank row, so
+                                        // the ds_read_b128 of the four channel groups are conflict-free)
 #define PK_BUF (SC_W * 2 * PK_TILE)     // dwords per buffer
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
@@ -60,7 +66,15 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     float* acc = smem + 4 * TILE;
     constexpr bool PACKED = SC_SLAB_PACKED && sizeof(T) == 2 && SC_W == 8 && SC_SLAB_BUFS == 2;
     uint32_t* accp = (uint32_t*)acc;
+    static_assert(!PACKED || SC_S == 8, "packed slab: two 4-item blocks per lane");
     const int lane = threadIdx.x & 63;
+    // selection matrix of the MFMA flush (see PK_TILE): row i = lane & 15 picks element pi(i & 7) of every piece
+    u32x4 selA = {0u, 0u, 0u, 0u};
+    if constexpr (PACKED) {
+        const uint32_t one = 0x3F80u << (16 * ((lane >> 2) & 1));  // bf16 1.0 in the low / high half
+        selA[0] = (lane & 3) == 0 ? one : 0u, selA[1] = (lane & 3) == 1 ? one : 0u;
+        selA[2] = (lane & 3) == 2 ? one : 0u, selA[3] = (lane & 3) == 3 ? one : 0u;
+    }
     const int wave = cad_uniform(threadIdx.x >> 6);
     const int64_t sb = blockIdx.y;
     const int e_raw = blockIdx.x * SC_W + wave;
@@ -130,9 +144,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     float dDacc = 0.f, dbacc = 0.f;
     int tix = 0;
 
+    SC_TIME_DECL;
     for (int64_t c = nchunks - 1; c >= 0; --c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
+        SC_TIME(0);  // flush tail of the previous pair-step / loop overhead
         float ddt[SC_S], gBs[SC_S];   // sum over the states of g * h_{i-1} * a * A  and of  <g, B>
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
@@ -147,6 +163,17 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 // out = y * z * sigmoid(z)  =>  y * sigmoid(z) = out / z ;  dz = dout * y * sigmoid(z) * (1 + z (1 - sigmoid(z)))
                 float zz[SC_S], oo[SC_S], dzv[SC_S];
                 sc_unpack<T, SC_S>(z_raw, rev, zz);
+                if (a.gate_fix_list) {
+                    // out / z cannot recover y where the gate is exactly 0 (out == 0 there): remember the chunk, the
+                    // fix-up launch (cad_scan_bwd_gate_fix) recomputes y for it and adds dout * y / 2 to dz
+                    bool z0 = false;
+#pragma unroll
+                    for (int i = 0; i < SC_S; ++i) z0 = z0 || (zz[i] == 0.f && p0 + i < L);
+                    if (cad_wave_any(z0 && act) && lane == 0) {
+                        const int slot = atomicAdd(a.gate_fix_count, 1);
+                        a.gate_fix_list[slot] = (int64_t)e | ((int64_t)sb << 20) | ((int64_t)c << 40);
+                    }
+                }
                 if (o_row) {  // wave-uniform: this set writes the gate gradient
                     sc_unpack<T, SC_S>(o_raw, rev, oo);
                     if (o2_row) {  // ... of both scans sharing the gate
@@ -187,6 +214,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c - 1) * NP + lane) * 2;
             hin_next = f2(stp[0], stp[1]);
         }
+        SC_TIME(1);  // chunk prologue: unpack, gate, softplus
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);
@@ -213,6 +241,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             f32x2 Cv[SC_S], Bw[SC_S];
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
+            SC_TIME(2);  // staging issue + B/C tile reads
             // 1. forward recompute: serial totals, wave scan, then the true h_i
             f32x2 av[SC_S], hs[SC_S];
             f32x2 acc_h = f2(0.f);
@@ -223,6 +252,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 hs[i] = splat_hi(dd[i]) * Bw[i];  // b_i
                 acc_h = av[i] * acc_h + hs[i];
             }
+            SC_TIME(3);  // exp + serial scan
             f32x2 PA = acc_a, PH = acc_h;
             wave_scan_fwd(PA, PH);
             const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
@@ -230,6 +260,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const f32x2 h0 = ea * hin + eh;  // state entering this lane's segment
             // the true h_i (forward chain) and 2. the reverse scan of G (backward chain), interleaved: two independent
             // serial v_pk_fma chains, each step of one fills the wait state the other needs between dependent packed ops
+            SC_TIME(4);  // forward wave scan
             f32x2 RG = f2(0.f);
             {
                 f32x2 h = h0;
@@ -241,6 +272,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     hs[i] = h;  // h_i
                 }
             }
+            SC_TIME(5);  // true h + lane-local reverse scan
             f32x2 QA = acc_a, QG = RG;
             wave_scan_rev(QA, QG, lane);
             const f32x2 fa = f2(dpp_wave_shl1(1.f, QA[0]), dpp_wave_shl1(1.f, QA[1]));
@@ -249,6 +281,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             f32x2 G = fa * gin + fg;  // G_{i+1} for this lane's last item
             const f32x2 newc = readlane2(QA * gin + QG, 0);
             if (lane == np) carryG = newc;
+            SC_TIME(6);  // reverse wave scan + carry
             // 3. gradients
             f32x2 dAp = f2(0.f);
             uint32_t pkB = 0, pkC = 0;
@@ -269,7 +302,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     if (i & 1) {
                         pkB = pB, pkC = pC;  // the odd item waits for its even partner: one 8-byte store per item pair
                     } else {
-                        uint32_t* qB = accp + buf * PK_BUF + wave * 2 * PK_TILE + (i >> 1) * PK_IPS + lane * 2;
+                        uint32_t* qB = accp + buf * PK_BUF + wave * 2 * PK_TILE + (i >> 2) * PK_Q + lane * 4 + ((i >> 1) & 1) * 2;
                         *(u32x2*)qB = u32x2{pB, pkB};
                         *(u32x2*)(qB + PK_TILE) = u32x2{pC, pkC};
                     }
@@ -278,6 +311,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     *(f32x2*)(aC + i * ACC_ISTR) = dCv;
                 }
             }
+            SC_TIME(7);  // gradient loop + slab writes
             dAp = wave_sum2_dpp(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
             if (np == NP - 1) {
@@ -300,8 +334,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
                 }
             }
+            SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
             if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev);
+            SC_TIME(9);  // staging store (waits for the tile loads)
             __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
+            SC_TIME(10);  // barrier wait
             if (np == NP - 1 && c > 0) {
                 // the item vectors of the next (earlier) chunk: issued now, they land behind this pair's flush and the
                 // chunk epilogue instead of stalling the next chunk's start
@@ -317,35 +354,42 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // consecutive positions, stored 4 at a time (8/16-byte stores).  With two slab buffers the next pair writes
             // the other buffer, so one barrier per pair suffices.
             if constexpr (PACKED) {
-                // thread t owns one tensor and the positions (lane j, items 2ip, 2ip + 1): 8 ds_read_b64 (one per channel),
-                // each {item 2ip: states 0|1, item 2ip + 1: states 0|1}; two 4-byte stores (one per state row)
-                const int t = threadIdx.x;
-                const int ten = t >> 8, j = (t & 255) >> 2, ip = t & 3;
-                const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + ip * PK_IPS + j * 2;
-                float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;  // s<item><state>
+                // wave w sums tensor (w >> 2), lanes 16 (w & 3) .. + 15 over the 8 channels on the matrix core
+                const int ten = wave >> 2, jb = wave & 3;
+                const int g = lane >> 4, jl = lane & 15;
+                const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + (jb * 16 + jl) * 4 + g * (2 * PK_TILE);
+                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int w = 0; w < SC_W; ++w) {
-                    const u32x2 v = *(const u32x2*)(src + w * 2 * PK_TILE);
-                    s00 += cad_bits2f(v[0] << 16), s01 += cad_bits2f(v[0] & 0xFFFF0000u);
-                    s10 += cad_bits2f(v[1] << 16), s11 += cad_bits2f(v[1] & 0xFFFF0000u);
+                for (int hf = 0; hf < 2; ++hf) {
+                    const u32x4 b0 = *(const u32x4*)(src + hf * (8 * PK_TILE));
+                    const u32x4 b1 = *(const u32x4*)(src + hf * (8 * PK_TILE) + PK_Q);
+                    d0 = cad_mfma_16x16x32_bf16(selA, b0, d0);
+                    d1 = cad_mfma_16x16x32_bf16(selA, b1, d1);
                 }
-                const int64_t p = base + j * SC_S + 2 * ip;
-                T* grow = (ten ? dCg : dBg) + ((int64_t)n0 * SB + sb) * L;
-                const int64_t srow = SB * L;  // next state's row
-                if (VEC) {
-                    if (p < L) {
-                        const int64_t q = rev ? (L - p - 2) : p;
-                        *(uint32_t*)(grow + q) = rev ? cad_pack_bf16x2(s10, s00) : cad_pack_bf16x2(s00, s10);
-                        if (n0 + 1 < N) *(uint32_t*)(grow + srow + q) = rev ? cad_pack_bf16x2(s11, s01) : cad_pack_bf16x2(s01, s11);
-                    }
-                } else {
-                    if (p < L) {
-                        grow[cad_phys(p, L, rev)] = from_f32<T>(s00);
-                        if (n0 + 1 < N) grow[srow + cad_phys(p, L, rev)] = from_f32<T>(s01);
-                    }
-                    if (p + 1 < L) {
-                        grow[cad_phys(p + 1, L, rev)] = from_f32<T>(s10);
-                        if (n0 + 1 < N) grow[srow + cad_phys(p + 1, L, rev)] = from_f32<T>(s11);
+                // lanes 0..31: g = state of the pair; d0 = items 0..3, d1 = items 4..7 of lane (jb, jl)
+                if (g < 2 && n0 + g < N) {
+                    const int64_t p = base + (int64_t)(jb * 16 + jl) * SC_S;
+                    // row (state n0 + g) of this workgroup's slot: scalar base + one per-lane select (g is 0 or 1 here)
+                    T* grow = (ten ? dCg : dBg) + ((int64_t)n0 * SB + sb) * L + (g ? SB * L : (int64_t)0);
+                    if (VEC) {
+                        if (p < L) {
+                            u32x4 o;
+                            if (rev) {
+                                o[0] = cad_pack_bf16x2_safe(d1[3], d1[2]), o[1] = cad_pack_bf16x2_safe(d1[1], d1[0]);
+                                o[2] = cad_pack_bf16x2_safe(d0[3], d0[2]), o[3] = cad_pack_bf16x2_safe(d0[1], d0[0]);
+                                *(u32x4*)(grow + (L - p - SC_S)) = o;
+                            } else {
+                                o[0] = cad_pack_bf16x2_safe(d0[0], d0[1]), o[1] = cad_pack_bf16x2_safe(d0[2], d0[3]);
+                                o[2] = cad_pack_bf16x2_safe(d1[0], d1[1]), o[3] = cad_pack_bf16x2_safe(d1[2], d1[3]);
+                                *(u32x4*)(grow + p) = o;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (p + q < L) grow[cad_phys(p + q, L, rev)] = from_f32<T>(d0[q]);
+                            if (p + 4 + q < L) grow[cad_phys(p + 4 + q, L, rev)] = from_f32<T>(d1[q]);
+                        }
                     }
                 }
             } else {
@@ -388,6 +432,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }
             }
             if (SC_SLAB_BUFS == 1) __syncthreads();  // the slab is rewritten by the next pair
+            SC_TIME(11);  // next chunk's loads issued + flush
         }
     }
     if (a.dh0 && act && lane < NP) {  // gradient w.r.t. the state entering the row
@@ -406,6 +451,85 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     if (act && lane == 0) {
         if (a.dD) atomicAdd(a.dD + e, dDacc);
         if (a.ddelta_bias) atomicAdd(a.ddelta_bias + e, dbacc);
+    }
+}
+
+// Gate gradient where z == 0 exactly (see the worklist in scan_bwd_kernel): one wave per recorded (channel, row, chunk)
+// recomputes the UNGATED y of that chunk from the saved chunk state (serial scan + DPP wave scan, as the forward) and
+// adds  dout * y * sigmoid(0) = dout * y / 2  to dz at the positions whose gate is 0.  Rare path: element-wise loads.
+template <typename T>
+__global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const int count = *a.gate_fix_count;
+    const int64_t L = a.L, SB = a.SB;
+    const int N = a.N, NP = (N + 1) >> 1;
+    const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
+    for (int idx = blockIdx.x * 4 + wave; idx < count; idx += gridDim.x * 4) {
+        const int64_t ent = a.gate_fix_list[idx];
+        const int e = (int)(ent & 0xFFFFF);
+        const int64_t sb = (ent >> 20) & 0xFFFFF, c = ent >> 40;
+        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
+        const int64_t row_off = ((int64_t)e * SB + sb) * L;
+        const T* u_row = (const T*)a.u + row_off;
+        const T* d_row = (const T*)a.delta + row_off;
+        const T* z_row = (const T*)a.z + row_off;
+        const T* g_row = (const T*)a.dout + row_off;
+        T* dz_row = (T*)a.gate_fix_dz + row_off;
+        const float Dv = a.D ? a.D[e] : 0.f;
+        const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
+        const int64_t p0 = c * SC_CHUNK + (int64_t)lane * SC_S;
+        float y[SC_S];
+        f32x2 dd[SC_S];
+#pragma unroll
+        for (int i = 0; i < SC_S; ++i) {
+            const bool ok = p0 + i < L;
+            const int64_t l = ok ? cad_phys(p0 + i, L, rev) : 0;
+            const float ui = ok ? to_f32(u_row[l]) : 0.f;
+            const float dti = ok ? cad_softplus(to_f32(d_row[l]) + bias) : 0.f;
+            y[i] = Dv * ui;
+            dd[i] = f2(dti, dti * ui);
+        }
+        for (int np = 0; np < NP; ++np) {
+            const int n0 = 2 * np;
+            const bool two = n0 + 1 < N;
+            const f32x2 A2 = f2(a.A[e * N + n0], two ? a.A[e * N + n0 + 1] : 0.f) * f2(CAD_LOG2E);
+            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + np) * 2;
+            const f32x2 hin = f2(stp[0], stp[1]);
+            const T* Brow = (const T*)a.Bm + ((int64_t)n0 * SB + sb) * L;
+            const T* Crow = (const T*)a.Cm + ((int64_t)n0 * SB + sb) * L;
+            f32x2 av[SC_S], bv[SC_S], Cv[SC_S];
+            f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                const bool ok = p0 + i < L;
+                const int64_t l = ok ? cad_phys(p0 + i, L, rev) : 0;
+                const f32x2 Bv = ok ? f2(to_f32(Brow[l]), two ? to_f32(Brow[SB * L + l]) : 0.f) : f2(0.f);
+                Cv[i] = ok ? f2(to_f32(Crow[l]), two ? to_f32(Crow[SB * L + l]) : 0.f) : f2(0.f);
+                av[i] = exp2_2(splat_lo(dd[i]) * A2);
+                bv[i] = splat_hi(dd[i]) * Bv;
+                acc_h = av[i] * acc_h + bv[i];
+                acc_a = acc_a * av[i];
+            }
+            f32x2 PA = acc_a, PH = acc_h;
+            wave_scan_fwd(PA, PH);
+            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
+            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
+            f32x2 h = ea * hin + eh;
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                h = av[i] * h + bv[i];
+                y[i] += dot2(Cv[i], h);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SC_S; ++i) {
+            if (p0 + i < L) {
+                const int64_t l = cad_phys(p0 + i, L, rev);
+                if (to_f32(z_row[l]) == 0.f)
+                    dz_row[l] = from_f32<T>(to_f32(dz_row[l]) + 0.5f * to_f32(g_row[l]) * y[i]);
+            }
+        }
     }
 }
 
@@ -449,6 +573,8 @@ __global__ void reduce_partials_kernel(const T* src, int nparts, int64_t n, T* d
 }
 
 }  // namespace
+
+SC_TIME_EXPORT(cad_debug_timing_bwd)
 
 extern "C" int cad_scan_bwd_partials(int E) { return (E + SC_W - 1) / SC_W; }
 
@@ -498,6 +624,28 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
 }
 
 extern "C" int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream) { return cad_scan_bwd_multi(a, 1, stream); }
+
+extern "C" int64_t cad_scan_gate_fix_entries(int E, int64_t SB, int64_t L) {
+    return (int64_t)E * SB * ((L + SC_CHUNK - 1) / SC_CHUNK);
+}
+
+extern "C" int cad_scan_bwd_gate_fix(const cad_scan_bwd_args* sets, int nsets, void* stream) {
+    CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= SC_MAXSETS);
+    for (int i = 0; i < nsets; ++i) {  // one launch per set, in order: sets sharing a dz buffer add to it one after the other
+        const cad_scan_bwd_args* a = &sets[i];
+        if (!a->gate_fix_list) continue;
+        CAD_CHECK_ARG(a->gate_fix_count && a->gate_fix_dz && a->z && a->chunk_state);
+        CAD_CHECK_ARG(a->E <= (1 << 20) && a->SB <= (1 << 20));
+        dim3 grid(256), block(256);
+        if (a->dtype == CAD_F32)
+            CAD_LAUNCH((scan_gate_fix_kernel<float>), grid, block, 0, stream, *a);
+        else if (a->dtype == CAD_BF16)
+            CAD_LAUNCH((scan_gate_fix_kernel<bf16_t>), grid, block, 0, stream, *a);
+        else
+            return CAD_ERR_UNSUPPORTED;
+    }
+    return cad_after_launch();
+}
 
 extern "C" int cad_reduce_partials(const void* src, int n_partials, int64_t n, void* dst, int dst_dtype, void* stream) {
     CAD_CHECK_ARG(src && dst && n_partials >= 1 && n > 0);

@@ -41,6 +41,37 @@
 #define SC_TILE(S) (64 * SC_ROW(S))    // floats per tile
 #define SC_SV(S) ((64 * (S)) / 128)    // tokens per staging thread (2 tensors x 128 threads x SC_SV tokens = one tile)
 
+// ---- phase timing (diagnostic builds only: -DSC_TIMING; tools/phase_timing.py) -----------------------------------------
+// Every wave of workgroup (0,0,0) adds the shader-clock cycles it spent between two marks to sc_timing[wave][phase];
+// the marks are scheduling barriers, so the build is for ATTRIBUTING time (incl. stalls) to phases, not for speed.
+#if defined(SC_TIMING) && !defined(CAD_EMU)
+#define SC_TIME_PHASES 16
+static __device__ unsigned long long sc_timing[8][SC_TIME_PHASES];
+#define SC_TIME_DECL unsigned long long sc_t_last_ = __builtin_readcyclecounter()
+#define SC_TIME(ph)                                                                                     \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        const unsigned long long t_ = __builtin_readcyclecounter();                                     \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)           \
+            atomicAdd(&sc_timing[(threadIdx.x >> 6) & 7][(ph)], t_ - sc_t_last_);                       \
+        sc_t_last_ = __builtin_readcyclecounter();                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+#define SC_TIME_EXPORT(name)                                                                            \
+    extern "C" int name(unsigned long long* out, int reset) {                                           \
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_timing), sizeof(sc_timing)) != hipSuccess) return 3;   \
+        if (reset) {                                                                                    \
+            static unsigned long long z[8][SC_TIME_PHASES];                                             \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(sc_timing), z, sizeof(z)) != hipSuccess) return 3;          \
+        }                                                                                               \
+        return 0;                                                                                       \
+    }
+#else
+#define SC_TIME_DECL
+#define SC_TIME(ph)
+#define SC_TIME_EXPORT(name)
+#endif
+
 __device__ __forceinline__ f32x2 f2(float a) {
     f32x2 r = {a, a};
     return r;

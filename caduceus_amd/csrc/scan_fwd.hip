@@ -96,9 +96,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         Areg = f2(a.A[e * N + n0] * CAD_LOG2E, (n0 + 1 < N) ? a.A[e * N + n0 + 1] * CAD_LOG2E : 0.f);
     }
     int tix = 0;            // tiles consumed so far: tile tix lives in LDS buffer tix & 1
+    SC_TIME_DECL;
     for (int64_t c = 0; c < nchunks; ++c) {
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
+        SC_TIME(0);  // chunk epilogue of the previous chunk (gate, store)
         float du[SC_S], dt[SC_S], y[SC_S];
         f32x2 y2[SC_S];  // per item: the output's even-state / odd-state partial sums (one v_pk_fma per item and pair)
         f32x2 dd[SC_S];  // (dt, dt * u)
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             st_base[lane * 2] = carry[0];
             st_base[lane * 2 + 1] = carry[1];
         }
+        SC_TIME(1);  // chunk prologue: loads, unpack, softplus
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & (RING - 1);
             // prefetch the tile AHEAD pairs from now (this chunk's or the next one's)
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
                 ha[i] = acc_a;
                 hh[i] = acc_h;
             }
+            SC_TIME(2);  // staging issue + exp + serial scan (B tile reads)
             // (ii) inclusive scan of the affine maps across lanes (DPP)
             f32x2 PA = acc_a, PH = acc_h;
             wave_scan_fwd(PA, PH);
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             }
             const f32x2 newc = readlane2(PA * hin + PH, 63);
             if (lane == np) carry = newc;
+            SC_TIME(3);  // wave scan + carry
             cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
@@ -179,11 +184,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
             }
+            SC_TIME(4);  // output phase (C tile reads)
             if (more) {
                 sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev);
                 SC_FWD_ADVANCE();
             }
+            SC_TIME(5);  // staging store
             if (((tix + 1) & (AHEAD - 1)) == 0) __syncthreads();
+            SC_TIME(6);  // barrier
         }
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) y[i] = y2[i][0] + y2[i][1];
@@ -212,6 +220,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 }
 
 }  // namespace
+
+SC_TIME_EXPORT(cad_debug_timing_fwd)
 
 static_assert(SC_CHUNK == SC_STATE_STEP || SC_CHUNK == 2 * SC_STATE_STEP, "forward chunk = one or two state slots");
 

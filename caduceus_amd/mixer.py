@@ -190,7 +190,11 @@ class BiMambaMixerFn(torch.autograd.Function):
         for i in range(2):  # per set: dA, dD, ddelta_bias (scan), dw, db (conv): accumulated by the kernels -> zeroed
             _, _, A_, _, Df_, bfz_, wf_, bf_ = sets[i][:8]
             zshapes += [A_.shape, Df_.shape, bfz_.shape, wf_.shape, (bf_.shape if bf_ is not None else (0,))]
+        zshapes += [(1,), (1,)]  # worklist counters of the exact z == 0 gate gradient (int32 views of zero bits)
         zbuf = _zeros_f32(zshapes, x2d.device)
+        fix_cnt = [zbuf[10].view(torch.int32), zbuf[11].view(torch.int32)]
+        n_fix = lib.cad_scan_gate_fix_entries(E, SB, Lq)
+        fix_list = [torch.empty((n_fix,), dtype=torch.int64, device=x2d.device) for _ in range(2)]
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
             N = A.shape[1]
@@ -208,9 +212,11 @@ class BiMambaMixerFn(torch.autograd.Function):
                                     L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
                                     L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
                                     dirs[i][0], dirs[i][1], L.dtype_code(act), npart, None, None,
-                                    L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None)
+                                    L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None, L.ptr(fix_list[i]),
+                                    L.ptr(fix_cnt[i]), L.ptr(dxz[E:]) if (_SHARED_GATE or i == 0) else L.ptr(dz))
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
         L.check(lib.cad_scan_bwd_multi(args, 2, stream), "cad_scan_bwd_multi")
+        L.check(lib.cad_scan_bwd_gate_fix(args, 2, stream), "cad_scan_bwd_gate_fix")  # no-op unless some z == 0 exactly
         grads, dxcs, part = [], [], []
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]

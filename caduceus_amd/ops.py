@@ -161,6 +161,14 @@ def causal_conv1d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
 # ------------------------------------------------------------------------------------------------------------------
 # selective scan
 # ------------------------------------------------------------------------------------------------------------------
+def gate_fix_buffers(lib, u, N):
+    """Worklist (int64 slots) + zeroed counter (int32) for the exact gate gradient at z == 0 (cad_scan_bwd_gate_fix)."""
+    E, SB, Lq = u.shape
+    lst = torch.empty((lib.cad_scan_gate_fix_entries(E, SB, Lq),), dtype=torch.int64, device=u.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=u.device)
+    return lst, cnt
+
+
 class _ScanMulti(torch.autograd.Function):
     """1 or 2 parameter sets (same shapes, shared gate z) in one launch.  Tensor args per set:
     u, delta, A, Bm, Cm, D, delta_bias."""
@@ -217,13 +225,17 @@ class _ScanMulti(torch.autograd.Function):
             dBC = torch.empty((2, npart, N, SB, Lq), dtype=u.dtype, device=u.device)
             stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dBC, dD, dbias)
             rl, rh = dirs[i]
+            fix_list, fix_cnt = gate_fix_buffers(lib, u, N) if z is not None else (None, None)
             args[i] = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
                                     L.ptr(bf), L.ptr(dout), L.ptr(fout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz),
                                     L.ptr(dA), L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
-                                    rl, rh, L.dtype_code(u.dtype), npart)
-            keep.append((dout, dBC))
+                                    rl, rh, L.dtype_code(u.dtype), npart, None, None, None, L.ptr(fix_list),
+                                    L.ptr(fix_cnt), L.ptr(dz))
+            keep.append((dout, dBC, fix_list, fix_cnt))
             res.append([du, ddelta, dA, dBC, dD, dbias, dz])
         L.check(lib.cad_scan_bwd_multi(args, nsets, stream), "cad_scan_bwd_multi")
+        if z is not None:  # exact gate gradient where z == 0 (rare; the launch is a no-op otherwise)
+            L.check(lib.cad_scan_bwd_gate_fix(args, nsets, stream), "cad_scan_bwd_gate_fix")
         grads = []
         dz_tot = None
         for i in range(nsets):
@@ -299,11 +311,15 @@ class _ScanStateful(torch.autograd.Function):
         dBC = torch.empty((2, npart, N, SB, Lq), dtype=u.dtype, device=u.device)
         dh0 = torch.empty((E, SB, N), dtype=torch.float32, device=u.device)
         stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, dout, state, du, ddelta, dz, dA, dBC, dD, dbias, dhT, dh0)
+        fix_list, fix_cnt = gate_fix_buffers(lib, u, N) if z is not None else (None, None)
         a = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
                           L.ptr(dout), L.ptr(fout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
                           L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N, rev_lo, rev_hi,
-                          L.dtype_code(u.dtype), npart, L.ptr(dhT), L.ptr(dh0))
+                          L.dtype_code(u.dtype), npart, L.ptr(dhT), L.ptr(dh0), None, L.ptr(fix_list), L.ptr(fix_cnt),
+                          L.ptr(dz))
         L.check(lib.cad_scan_bwd(C.byref(a), stream), "cad_scan_bwd")
+        if z is not None:
+            L.check(lib.cad_scan_bwd_gate_fix(C.byref(a), 1, stream), "cad_scan_bwd_gate_fix")
         n = dBC[0, 0].numel()
         dB, dC = torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device), \
             torch.empty(dBC.shape[2:], dtype=u.dtype, device=u.device)
@@ -374,9 +390,13 @@ class _LmHead(torch.autograd.Function):
         logits = torch.empty(hidden.shape[1:-1] + (V,), dtype=torch.float32, device=hidden.device)
         lab = None if labels is None else labels.reshape(-1).long().contiguous()
         acc = torch.zeros((2,), dtype=torch.float32, device=hidden.device)
-        stream = L.stream_and_check(hidden, w, comp, lab, logits, acc)
+        # deterministic loss: per-workgroup partial sums folded in a fixed order (no fp32 atomics)
+        parts = (torch.empty((L.get_lib().cad_lm_head_partials(rows),), dtype=torch.float32, device=hidden.device)
+                 if labels is not None else None)
+        stream = L.stream_and_check(hidden, w, comp, lab, logits, acc, parts)
         a = L.LmHeadArgs(L.ptr(hidden), L.ptr(w), L.ptr(comp), L.ptr(lab), L.ptr(logits), C.c_void_p(acc.data_ptr()),
-                         C.c_void_p(acc.data_ptr() + 4), rows, D, V, S, int(ignore_index), L.dtype_code(hidden.dtype))
+                         C.c_void_p(acc.data_ptr() + 4), rows, D, V, S, int(ignore_index), L.dtype_code(hidden.dtype),
+                         L.ptr(parts))
         L.check(L.get_lib().cad_lm_head_fwd(C.byref(a), stream), "cad_lm_head_fwd")
         loss = acc[0] / acc[1] if labels is not None else acc[0]
         ctx.save_for_backward(hidden, w, comp, lab, logits, acc)

@@ -210,7 +210,12 @@ int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
  * slot k is WRITTEN (plain coalesced stores, no atomics, no zeroing needed) with the sum over the channels of workgroup
  * k; cad_reduce_partials folds the slots (fp32 accumulation) into the final (N,SB,L) gradient.
  * chunk_state: as written by the forward.  out: the forward's (gated) output, required when z != NULL: the gate gradient
- * uses y = out / silu(z) instead of re-accumulating y (dz is 0 where z == 0 exactly).
+ * uses y = out / silu(z) instead of re-accumulating y.  Where z == 0 EXACTLY that quotient is 0/0: the kernel writes 0
+ * there and, when gate_fix_list / gate_fix_count are given, records the (channel, row, chunk) in the list;
+ * cad_scan_bwd_gate_fix (same argument structs, called after cad_scan_bwd[_multi] on the same stream) recomputes y for
+ * the recorded chunks and adds the exact dout * y / 2 into gate_fix_dz (= dz, or the dz buffer of the set that shares the
+ * gate).  gate_fix_list: cad_scan_gate_fix_entries(E, SB, L) int64 slots; gate_fix_count: one int32 the caller zeroes.
+ * Without them dz stays 0 where z == 0.
  * Optional carries (E, SB, N) fp32: dhT = gradient w.r.t. the forward's hT (default 0), dh0 = gradient w.r.t. h0 (written).
  * Shared gate (BiMamba: the forward and the reverse scan are gated by the same z and receive the same dout): pass the
  * other scan's gated output as out2 and dz receives the gate gradient of BOTH scans (one fp32 evaluation, one rounding);
@@ -243,9 +248,14 @@ typedef struct {
     const float* dhT;
     float* dh0;
     const void* out2;
+    int64_t* gate_fix_list;
+    int* gate_fix_count;
+    void* gate_fix_dz;
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
+int cad_scan_bwd_gate_fix(const cad_scan_bwd_args* sets, int nsets, void* stream);
+int64_t cad_scan_gate_fix_entries(int E, int64_t SB, int64_t L);
 int cad_scan_bwd_partials(int E);
 /* dst[i] = sum_k src[k*n + i], k < n_partials (fp32 accumulation); src and dst in dtype (fp32 or bf16). */
 int cad_reduce_partials(const void* src, int n_partials, int64_t n, void* dst, int dtype, void* stream);
@@ -295,7 +305,10 @@ int64_t cad_scan_tm_scratch_floats(int E, int64_t SB, int64_t L, int N);
  * src/tasks/metrics.py:181-184).  t-frame:  logits[b,l,v] = <W[v], t1[b,l]> + <W[comp[v]], t2[b,l]>.
  * hidden: (S, B*L, D) dtype.  W: (V, D) fp32.  logits: (B*L, V) fp32 (always written).
  * If labels != NULL: loss_sum[0] += sum over tokens with label != ignore_index of -log softmax[label],
- * count[0] += number of such tokens (both ACCUMULATED; caller zeroes; loss = loss_sum / count). */
+ * count[0] += number of such tokens (both ACCUMULATED; caller zeroes; loss = loss_sum / count).
+ * block_partials: scratch of cad_lm_head_partials(rows) floats, or NULL.  With it the sum is DETERMINISTIC (one slot per
+ * workgroup, folded by a second launch in a fixed order: run-to-run identical bits); NULL falls back to two fp32
+ * atomics per workgroup (order-dependent rounding in the last bits). */
 typedef struct {
     const void* hidden;
     const float* weight;
@@ -308,8 +321,10 @@ typedef struct {
     int D, V, n_strands;
     int64_t ignore_index;
     int dtype;
+    float* block_partials;
 } cad_lm_head_args;
 int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream);
+int64_t cad_lm_head_partials(int64_t rows);
 
 /* ---------------------------------------------------------------------------------------------------------
  * hg38 data path -- the step in front of the model.

@@ -342,3 +342,54 @@ def test_scan_state_carries_chain_segments(backend, dtype, cut):
         scale = max(1.0, float(r_.grad.abs().max()))
         torch.testing.assert_close(a_.grad.float(), r_.grad.float(), rtol=tol["rtol"], atol=tol["atol"] * scale,
                                    msg=lambda m, k=k: f"d{k}: {m}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_gate_exact_zero(backend, dtype):
+    """z == 0 exactly: out is 0 there, so y cannot be recovered from out / z; the fix-up launch recomputes y and adds
+    dout * y / 2 (the true gate gradient).  Zeros are scattered, fill whole positions (a zero in_proj row), and sit in
+    several chunks; every other gradient must be unaffected."""
+    name, dev = backend
+    E, SB, L, N, split, rl, rh = 5, 2, 1100, 16, 1, 0, 1
+    t = _scan_inputs(E, SB, L, N, 23, dev, dtype)
+    g = torch.Generator().manual_seed(5)
+    t["z"][torch.rand(E, SB, L, generator=g) < 0.02] = 0.0
+    t["z"][:, :, [0, 7, 511, 512, 700, L - 1]] = 0.0
+    t["z"][2, 1, :] = 0.0
+    order = ("u", "delta", "A", "B", "C", "D", "z", "bias")
+    act = {"u", "delta", "B", "C", "z"}
+    ins = [leaf(t[k], dev, dtype if k in act else torch.float32) for k in order]
+    out = ops.selective_scan(*ins, split, rl, rh)
+    (out.float() * t["w"].to(dev)).sum().backward()
+    ref_ins = [leaf(t[k], 'cpu') for k in order]
+    u, d, A, B, C, D, z, b = ref_ins
+    ref = _rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, A, B_, C_, D, z_, b), [u, d, B, C, z],
+                       split, rl, rh)
+    (ref * t["w"]).sum().backward()
+    tol = FP32 if dtype == torch.float32 else BF16
+    zero = (t["z"] == 0)
+    assert float(z.grad[zero].abs().max()) > 0.1  # the case is not vacuous
+    for k, a, r in zip(order, ins, ref_ins):
+        scale = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.float().cpu(), r.grad, rtol=tol["rtol"], atol=tol["atol"] * scale,
+                                   msg=lambda m, k=k: f"d{k}: {m}")
+    torch.testing.assert_close(ins[6].grad.float().cpu()[zero], z.grad[zero], rtol=tol["rtol"],
+                               atol=tol["atol"] * max(1.0, float(z.grad[zero].abs().max())))
+
+
+def test_lm_head_loss_is_deterministic(backend):
+    """The fused loss is a two-stage fixed-order sum: repeated runs give identical bits."""
+    name, dev = backend
+    g = torch.Generator().manual_seed(3)
+    S, B, L, D, V = 2, 2, 700, 32, 16
+    hidden = torch.randn(S, B, L, D, generator=g).to(dev)
+    w = torch.randn(V, D, generator=g).to(dev)
+    comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15]).to(dev)
+    labels = torch.randint(0, V, (B, L), generator=g)
+    labels[torch.rand(B, L, generator=g) < 0.8] = 4
+    labels = labels.to(dev)
+    losses = [ops.lm_head(hidden, w, comp, labels, 4)[1] for _ in range(4)]
+    assert all(torch.equal(losses[0], l) for l in losses[1:])
+    logits = ops.lm_head(hidden, w, comp, None, 4)[0]
+    ref = F.cross_entropy(logits.reshape(-1, V).cpu().double(), labels.reshape(-1).cpu(), ignore_index=4)
+    torch.testing.assert_close(losses[0].cpu().double(), ref, rtol=1e-5, atol=1e-6)

@@ -98,3 +98,48 @@ def test_inputs_embeds_and_hidden_states(backend):
     torch.testing.assert_close(a.hidden_states[-1].cpu(), rec["hidden"], **FP32)
     tup = model(ids, labels=rec["labels"].to(dev), return_dict=False)
     assert isinstance(tup, tuple) and tup[0].ndim == 0 and tup[1].shape == a.logits.shape
+
+
+def test_weighted_cross_entropy_path(backend):
+    """`loss_weights` (modeling_caduceus.py:286-294, 484-486): weighted CE over the non-ignored targets, and its gradients."""
+    _, dev = backend
+    model, cfg, sd, rec = build_model("ps_fused", dev)
+    ids, labels = rec["input_ids"].to(dev), rec["labels"].to(dev)
+    g = torch.Generator().manual_seed(7)
+    lw = torch.rand(labels.shape, generator=g) + 0.1
+    out = model(ids, labels=labels, loss_weights=lw.to(dev))
+    ref = om.masked_lm_forward(sd, rec["input_ids"], cfg)
+    ref_loss = om.weighted_cross_entropy(ref["logits"], rec["labels"], lw, ignore_index=4)
+    torch.testing.assert_close(out.loss.cpu(), ref_loss, **FP32)
+    out.loss.backward()
+    # gradient of the weighted loss w.r.t. the tied embedding, against autograd through the oracle
+    key = "caduceus.backbone.embeddings.word_embeddings.embedding.weight"
+    sd2 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    sd2["lm_head.lm_head.weight"] = sd2[key]
+    r2 = om.masked_lm_forward(sd2, rec["input_ids"], cfg)
+    om.weighted_cross_entropy(r2["logits"], rec["labels"], lw, ignore_index=4).backward()
+    got = model.state_dict(keep_vars=True)[key].grad.cpu()
+    want = sd2[key].grad
+    torch.testing.assert_close(got, want, rtol=6e-4, atol=2e-3 * max(1.0, float(want.abs().max())))
+
+
+def test_zero_hidden_rows_gate_gradient(backend):
+    """Zero rows of `inputs_embeds` make the in_proj gate exactly 0 for every channel of those tokens -- the case in which
+    out / z cannot recover y.  Through the production (shared-gate) mixer path the gradient w.r.t. the embeddings must
+    still match autograd through the oracle."""
+    _, dev = backend
+    model, cfg, sd, rec = build_model("ps_fused", dev)
+    ids = rec["input_ids"]
+    emb = om.rcps_embedding(sd["caduceus.backbone.embeddings.word_embeddings.embedding.weight"],
+                            sd["caduceus.backbone.embeddings.word_embeddings.complement_map"], ids).clone()
+    emb[:, [0, 5, 17, emb.shape[1] - 1]] = 0.0
+    w = torch.randn(emb.shape[0], emb.shape[1], cfg["d_model"] * 2, generator=torch.Generator().manual_seed(1))
+    x = emb.clone().to(dev).requires_grad_(True)
+    h = model.caduceus(inputs_embeds=x).last_hidden_state
+    (h * w.to(dev)).sum().backward()
+    xr = emb.clone().requires_grad_(True)
+    href, _ = om.backbone_forward(sd, None, cfg, inputs_embeds=xr)
+    (href * w).sum().backward()
+    torch.testing.assert_close(h.detach().cpu(), href.detach(), **FP32)
+    scale = max(1.0, float(xr.grad.abs().max()))
+    torch.testing.assert_close(x.grad.cpu(), xr.grad, rtol=6e-4, atol=2e-3 * scale)
