@@ -64,12 +64,16 @@ __global__ void tokenize_mlm_kernel(cad_mlm_args a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const int64_t b = idx / a.L, p = idx - b * a.L;
-        const int64_t len = a.lengths ? a.lengths[b] : a.L;  // valid bases of this row, left-padded to L
-        const int64_t q = p - (a.L - len);                   // position inside the sequence
+        const int64_t full = a.lengths ? a.lengths[b] : a.L;  // bases of this row
+        // a row longer than L keeps its FIRST L tokens: the reference tokenizer truncates on the right
+        // (truncation=True, default truncation_side; hg38_dataset.py:190-200) AFTER the reverse complement (:179-180),
+        // so the RC index below runs over the full length
+        const int64_t len = full < a.L ? full : a.L;           // tokens of this row, left-padded to L
+        const int64_t q = p - (a.L - len);                     // position inside the (truncated) sequence
         int id = a.pad_id;
         if (q >= 0) {
             const bool rc = a.rc_flags && a.rc_flags[b];
-            const uint8_t raw = a.bases[b * a.ld_bases + (rc ? len - 1 - q : q)];
+            const uint8_t raw = a.bases[b * a.ld_bases + (rc ? full - 1 - q : q)];
             id = base_id(rc ? comp_char(raw) : raw, a);
             if (id == a.n_id) id = a.pad_id;  // replace_value(N -> pad): ignored by the loss
         }

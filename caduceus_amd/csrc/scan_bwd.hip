@@ -49,6 +49,12 @@ struct ScanBwdSets {
 #define PK_TILE (2 * PK_Q)              // dwords per (wave, tensor) region (2 KB: a multiple of the 256-byte bank row, so
                                         // the ds_read_b128 of the four channel groups are conflict-free)
 #define PK_BUF (SC_W * 2 * PK_TILE)     // dwords per buffer
+// LDS-DMA prefetch of the next chunk's item vectors (bf16 production kernel): 6 vectors x SC_W waves x 64 lanes x 16 bytes
+#ifndef SC_BWD_PREFETCH
+#define SC_BWD_PREFETCH 1
+#endif
+#define PRE_SLOT (SC_W * 64 * 16)       // bytes per vector slot (all waves)
+#define PRE_BYTES (SC_NDMA * PRE_SLOT)
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
 #endif
@@ -67,6 +73,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     constexpr bool PACKED = SC_SLAB_PACKED && sizeof(T) == 2 && SC_W == 8 && SC_SLAB_BUFS == 2;
     uint32_t* accp = (uint32_t*)acc;
     static_assert(!PACKED || SC_S == 8, "packed slab: two 4-item blocks per lane");
+    // item vectors of the next chunk travel global -> LDS by DMA one chunk ahead (16-byte vectors: bf16, 8 items)
+    constexpr bool PREF = SC_BWD_PREFETCH && PACKED && VEC && SC_S * sizeof(T) == 16;
+    char* pre = (char*)(accp + 2 * PK_BUF);  // [vector 0..5][wave][lane][16 bytes], behind the two slab buffers
     const int lane = threadIdx.x & 63;
     // selection matrix of the MFMA flush (see PK_TILE): row i = lane & 15 picks element pi(i & 7) of every piece
     u32x4 selA = {0u, 0u, 0u, 0u};
@@ -114,15 +123,30 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         } else {
             sc_stage_load<T, SC_S, false>(st, sctx, 0, N, base, L, rev);
         }
-        sc_load_raw<T, SC_S, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
-        sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
-        sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
-        if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
-        if (o_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
-        if (o2_row) sc_load_raw<T, SC_S, VEC>(o2_row, base + (int64_t)lane * SC_S, L, rev, o2_raw);
+        if constexpr (!PREF) {
+            sc_load_raw<T, SC_S, VEC>(u_row, base + (int64_t)lane * SC_S, L, rev, u_raw);
+            sc_load_raw<T, SC_S, VEC>(d_row, base + (int64_t)lane * SC_S, L, rev, d_raw);
+            sc_load_raw<T, SC_S, VEC>(g_row, base + (int64_t)lane * SC_S, L, rev, g_raw);
+            if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, base + (int64_t)lane * SC_S, L, rev, z_raw);
+            if (o_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
+            if (o2_row) sc_load_raw<T, SC_S, VEC>(o2_row, base + (int64_t)lane * SC_S, L, rev, o2_raw);
+        }
         sc_stage_store<T, SC_S, VEC>(st, smem, rev);
     }
     __syncthreads();
+    // LDS-DMA of the item vectors of the chunk whose lane segment starts at logical position pq.  Always SC_NDMA
+    // operations (absent tensors re-fetch u into their slot) so that the counted wait of the staging path is exact.
+    const uint32_t pre_lds = cad_uniform((int)(sc_lds_off(pre) + wave * (64 * 16)));
+    auto prefetch_vectors = [&](int64_t pq) {
+        const int64_t l0 = pq < L ? (rev ? (L - pq - SC_S) : pq) : 0;  // clamped: out-of-range segments are zeroed at use
+        sc_glds16(u_row + l0, pre_lds);
+        sc_glds16(d_row + l0, pre_lds + PRE_SLOT);
+        sc_glds16(g_row + l0, pre_lds + 2 * PRE_SLOT);
+        sc_glds16((z_row ? z_row : u_row) + l0, pre_lds + 3 * PRE_SLOT);
+        sc_glds16((o_row ? o_row : u_row) + l0, pre_lds + 4 * PRE_SLOT);
+        sc_glds16((o2_row ? o2_row : u_row) + l0, pre_lds + 5 * PRE_SLOT);
+    };
+    if constexpr (PREF) prefetch_vectors((nchunks - 1) * SC_CHUNK + (int64_t)lane * SC_S);
 
     // lane np holds (A[2np], A[2np+1]); broadcast per pair with v_readlane (no memory access in the pair loop)
     f32x2 Areg = f2(0.f);
@@ -153,6 +177,22 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
+        if constexpr (PREF) {
+            // this chunk's vectors were fetched into LDS one chunk ago
+            sc_wait_all_loads();
+            const char* slot = pre + wave * (64 * 16) + lane * 16;
+            const bool in = p0 < L;
+            typedef ScVec<T, SC_S> V;
+            V zero;
+#pragma unroll
+            for (int j = 0; j < SC_S; ++j) zero.v[j] = from_f32<T>(0.f);
+            u_raw = in ? *(const V*)slot : zero;
+            d_raw = in ? *(const V*)(slot + PRE_SLOT) : zero;
+            g_raw = in ? *(const V*)(slot + 2 * PRE_SLOT) : zero;
+            if (z_row) z_raw = in ? *(const V*)(slot + 3 * PRE_SLOT) : zero;
+            if (o_row) o_raw = in ? *(const V*)(slot + 4 * PRE_SLOT) : zero;
+            if (o2_row) o2_raw = in ? *(const V*)(slot + 5 * PRE_SLOT) : zero;
+        }
         {
             float uu[SC_S], dt[SC_S], dy[SC_S];
             sc_unpack<T, SC_S>(u_raw, rev, uu);
@@ -227,6 +267,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 } else {
                     sc_stage_load<T, SC_S, false>(st, sctx, nn, N, nb, L, rev);
                 }
+            }
+            // the next (earlier) chunk's item vectors: by DMA into LDS, issued behind this pair-step's tile loads (the
+            // counted wait at the staging store lets them fly) and a whole chunk ahead of their use
+            const bool dma_now = PREF && np == 0 && c > 0;
+            if constexpr (PREF) {
+                if (dma_now) prefetch_vectors(p0 - SC_CHUNK);
             }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
@@ -335,11 +381,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }
             }
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
-            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev);
+            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
             SC_TIME(9);  // staging store (waits for the tile loads)
             __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             SC_TIME(10);  // barrier wait
-            if (np == NP - 1 && c > 0) {
+            if (!PREF && np == NP - 1 && c > 0) {
                 // the item vectors of the next (earlier) chunk: issued now, they land behind this pair's flush and the
                 // chunk epilogue instead of stalling the next chunk's start
                 const int64_t pn = p0 - SC_CHUNK;
@@ -606,20 +652,28 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
-    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) * sizeof(float);
+    const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
+    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) * sizeof(float) +
+                         (pref ? PRE_BYTES : 0);
+#define SC_BWD_LAUNCH(T, V)                                                      \
+    do {                                                                         \
+        SC_BIG_LDS((scan_bwd_kernel<T, V>), shmem);                              \
+        CAD_LAUNCH((scan_bwd_kernel<T, V>), grid, block, shmem, stream, ks);     \
+    } while (0)
     if (a->dtype == CAD_F32) {
         if (vec)
-            CAD_LAUNCH((scan_bwd_kernel<float, true>), grid, block, shmem, stream, ks);
+            SC_BWD_LAUNCH(float, true);
         else
-            CAD_LAUNCH((scan_bwd_kernel<float, false>), grid, block, shmem, stream, ks);
+            SC_BWD_LAUNCH(float, false);
     } else if (a->dtype == CAD_BF16) {
         if (vec)
-            CAD_LAUNCH((scan_bwd_kernel<bf16_t, true>), grid, block, shmem, stream, ks);
+            SC_BWD_LAUNCH(bf16_t, true);
         else
-            CAD_LAUNCH((scan_bwd_kernel<bf16_t, false>), grid, block, shmem, stream, ks);
+            SC_BWD_LAUNCH(bf16_t, false);
     } else {
         return CAD_ERR_UNSUPPORTED;
     }
+#undef SC_BWD_LAUNCH
     return cad_after_launch();
 }
 

@@ -396,6 +396,67 @@ __device__ __forceinline__ void sc_async_wait(V& a, V& b) {
     }
 #endif
 }
+// counted form of the wait above: returns as soon as at most `keep` vector-memory operations are outstanding.  Used in
+// the pair-step in which the LDS-DMA prefetch of the next chunk's item vectors (sc_glds16, SC_NDMA operations) was issued
+// BEHIND the tile loads: the tile loads are waited for, the prefetch stays in flight.
+#define SC_NDMA 6
+template <typename V>
+__device__ __forceinline__ void sc_async_wait_keep(V& a, V& b, bool keep_dma) {
+#ifndef CAD_EMU
+    static_assert(sizeof(V) == 8 || sizeof(V) == 16, "vector sizes of the prefetching kernels");
+    typedef uint32_t uw __attribute__((ext_vector_type(sizeof(V) / 4)));
+    uw x = __builtin_bit_cast(uw, a), y = __builtin_bit_cast(uw, b);
+    // ONE statement (the scalar branch on the wave-uniform flag is inside it): with the choice made in C++ the compiler
+    // materialises the "+v" operands in one arm BEFORE the wait, i.e. copies registers that are still in flight
+    // (caught by tests/test_isa_async.py)
+    const uint32_t k = __builtin_amdgcn_readfirstlane(keep_dma ? 1u : 0u);
+    asm volatile(
+        "s_cmp_eq_u32 %2, 0\n\t"
+        "s_cbranch_scc1 .Lsc_wait0_%=\n\t"
+        "s_waitcnt vmcnt(6)\n\t"
+        "s_branch .Lsc_waitd_%=\n"
+        ".Lsc_wait0_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n"
+        ".Lsc_waitd_%=:"
+        : "+v"(x), "+v"(y)
+        : "s"(k)
+        : "memory", "scc");
+    a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y);
+#endif
+}
+static_assert(SC_NDMA == 6, "the immediate of s_waitcnt vmcnt(6) above");
+
+// ---- LDS-DMA prefetch of the per-chunk item vectors -------------------------------------------------------------------
+// The u / delta / z / dout / out vectors of a chunk are needed at its very start; loaded there they expose the full HBM
+// latency once per chunk on every wave (measured: 19-32 % of the scan kernels, profiles/r02_phase_timing_mfma_flush.txt),
+// and the register file has no room for a second set.  global_load_lds_dwordx4 moves 16 bytes per lane from a per-lane
+// global address straight into LDS at (wave-uniform base) + 16 * lane without touching a VGPR, so the NEXT chunk's
+// vectors are fetched one whole chunk ahead into wave-private LDS slots and read back with ds_read_b128 when needed.
+// Completion is tracked by vmcnt like any load (the issuing wave waits vmcnt(0) before its ds_read).
+__device__ __forceinline__ uint32_t sc_lds_off(const void* p) {  // byte offset of an LDS object inside the LDS aperture
+#ifdef CAD_EMU
+    return (uint32_t)((const char*)p - emu::dyn_smem());
+#else
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+#endif
+}
+__device__ __forceinline__ void sc_glds16(const void* gsrc /* per lane */, uint32_t lds_base /* wave-uniform, SGPR */) {
+#ifdef CAD_EMU
+    std::memcpy(emu::dyn_smem() + lds_base + 16 * emu::lane_id(), gsrc, 16);
+#else
+    uint32_t keep;  // M0 holds the LDS base of the DMA; it is compiler-reserved, so save / restore it in the same statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+#endif
+}
+__device__ __forceinline__ void sc_wait_all_loads() {
+#ifndef CAD_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // Per-thread constants of the staging path, computed once per kernel: the thread's tensor base (+ its row sb) and its
 // first token inside a chunk.  Keeps the per-pair address arithmetic to one uniform multiply and two adds.
 template <typename T>
@@ -466,11 +527,16 @@ __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const S
 
 template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float* tiles /* B tile, C tile follows */,
-                                               int rev) {
+                                               int rev, bool keep_dma = false) {
     constexpr int SV = SC_SV(S);
     const int t = threadIdx.x;
     if (t >= 256) return;
-    if constexpr (VEC) sc_async_wait(r.s0, r.s1);
+    if constexpr (VEC) {
+        if constexpr (sizeof(StVec<T, SV>) <= 16)
+            sc_async_wait_keep(r.s0, r.s1, keep_dma);
+        else
+            sc_async_wait(r.s0, r.s1);
+    }
     float* tile = tiles + (t >> 7) * SC_TILE(S);
     const int tok = (t & 127) * SV;  // position inside the chunk
     float* dst = tile + (tok / S) * SC_ROW(S) + (tok % S) * 2;
@@ -513,3 +579,20 @@ __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float*
         dst[2 * j + 1] = r.ok1 ? to_f32(r.s1.v[k]) : 0.f;
     }
 }
+
+// more than 64 KB of dynamic LDS has to be requested per kernel (once)
+#if defined(CAD_EMU)
+#define SC_BIG_LDS(kern, bytes) (void)0
+#else
+#define SC_BIG_LDS(kern, bytes)                                                                                  \
+    do {                                                                                                             \
+        static bool done = false;                                                                                    \
+        if ((bytes) > 65536 && !done) {                                                                              \
+            if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != \
+                hipSuccess)                                                                                          \
+                return CAD_ERR_LAUNCH;                                                                                 \
+            done = true;                                                                                             \
+        }                                                                                                            \
+    } while (0)
+#endif
+

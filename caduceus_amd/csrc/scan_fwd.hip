@@ -16,9 +16,16 @@ struct ScanFwdSets {
 #ifndef SC_OCC_FWD
 #define SC_OCC_FWD SC_OCC
 #endif
-#ifndef SC_RING_FWD
-#define SC_RING_FWD 8
+// LDS-DMA prefetch of the next chunk's u / delta / z vectors (bf16 production kernel; see sc_glds16): 32-byte vectors =
+// two 16-byte planes per tensor; z is read at the END of a chunk, so it alternates between two slot pairs.
+#ifndef SC_FWD_DMA
+#define SC_FWD_DMA 1
 #endif
+#ifndef SC_RING_FWD
+#define SC_RING_FWD (SC_FWD_DMA ? 4 : 8)   // the prefetch slots take 64 KB of the LDS the deeper ring used (-1.7 %)
+#endif
+#define PRE_SLOT (SC_W * 64 * 16)          // bytes per 16-byte plane (all waves)
+#define PRE_BYTES (8 * PRE_SLOT)           // u0 u1 d0 d1 | z0 z1 (even chunks) | z0 z1 (odd chunks)
 
 template <typename T, bool VEC>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwdSets sets) {
@@ -48,6 +55,33 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
+    constexpr bool PREF = SC_FWD_DMA && VEC && SC_S * sizeof(T) == 32;
+    char* pre = (char*)(smem + RING * 2 * TILE);  // behind the tile ring
+    const uint32_t pre_lds = cad_uniform((int)(sc_lds_off(pre) + wave * (64 * 16)));
+    // SC_NDMA (= 6) DMA operations per chunk: u, delta, z (u again when there is no gate) x two 16-byte planes
+    auto prefetch_vectors = [&](int64_t cq) {
+        const int64_t pq = cq * SC_CHUNK + (int64_t)lane * SC_S;
+        const int64_t l0 = pq < L ? (rev ? (L - pq - SC_S) : pq) : 0;  // clamped: out-of-range segments are zeroed at use
+        const uint32_t zs = pre_lds + (4 + 2 * (uint32_t)(cq & 1)) * PRE_SLOT;
+        const T* zsrc = z_row ? z_row : u_row;
+        sc_glds16(u_row + l0, pre_lds);
+        sc_glds16(u_row + l0 + 8, pre_lds + PRE_SLOT);
+        sc_glds16(d_row + l0, pre_lds + 2 * PRE_SLOT);
+        sc_glds16(d_row + l0 + 8, pre_lds + 3 * PRE_SLOT);
+        sc_glds16(zsrc + l0, zs);
+        sc_glds16(zsrc + l0 + 8, zs + PRE_SLOT);
+    };
+    auto read_vector = [&](int plane0, int64_t p0, ScVec<T, SC_S>& out) {  // two ds_read_b128
+        struct __attribute__((aligned(16))) P { u32x4 a, b; };
+        static_assert(sizeof(P) == sizeof(ScVec<T, SC_S>) || !PREF, "two 16-byte planes per vector");
+        const char* slot = pre + wave * (64 * 16) + lane * 16 + plane0 * PRE_SLOT;
+        P v;
+        v.a = *(const u32x4*)slot, v.b = *(const u32x4*)(slot + PRE_SLOT);
+        const uint32_t m = p0 < L ? 0xFFFFFFFFu : 0u;  // bf16 zero = zero bits
+        const u32x4 mm = {m, m, m, m};
+        v.a &= mm, v.b &= mm;
+        if constexpr (sizeof(P) == sizeof(ScVec<T, SC_S>)) out = __builtin_bit_cast(ScVec<T, SC_S>, v);
+    };
 
     // software pipeline: the B/C tile of the NEXT (chunk, pair) and the u/delta/z vectors of the NEXT chunk are in
     // flight (registers) while the current pair is computed.
@@ -58,8 +92,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const int ntiles = (int)nchunks * NP;
     int s_np = 0;        // staging cursor: (chunk base, pair) of the next tile to stage
     int64_t s_base = 0;
-    sc_load_raw<T, SC_S, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
-    sc_load_raw<T, SC_S, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
+    if constexpr (PREF) {
+        prefetch_vectors(0);
+    } else {
+        sc_load_raw<T, SC_S, VEC>(u_row, (int64_t)lane * SC_S, L, rev, u_raw);
+        sc_load_raw<T, SC_S, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
+    }
     // stage the tile of the cursor / move the cursor on (wave-uniform)
 #define SC_FWD_STAGE()                                                                 \
     do {                                                                               \
@@ -105,7 +143,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         f32x2 y2[SC_S];  // per item: the output's even-state / odd-state partial sums (one v_pk_fma per item and pair)
         f32x2 dd[SC_S];  // (dt, dt * u)
 #ifndef SC_FWD_PREFETCH
-        if (c > 0) {
+        if constexpr (PREF) {
+            sc_wait_all_loads();  // this chunk's vectors were fetched into LDS one chunk ago
+            read_vector(0, p0, u_raw);
+            read_vector(2, p0, d_raw);
+        } else if (c > 0) {
             sc_load_raw<T, SC_S, VEC>(u_row, p0, L, rev, u_raw);
             sc_load_raw<T, SC_S, VEC>(d_row, p0, L, rev, d_raw);
         }
@@ -141,6 +183,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             // prefetch the tile AHEAD pairs from now (this chunk's or the next one's)
             const bool more = tix + AHEAD < ntiles;
             if (more) SC_FWD_STAGE();
+            // the next chunk's u / delta / z: DMA into LDS behind this pair-step's tile loads, a whole chunk ahead of use
+            const bool dma_now = PREF && np == 0 && c + 1 < nchunks;
+            if constexpr (PREF) {
+                if (dma_now) prefetch_vectors(c + 1);
+            }
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
             const f32x2 A2 = readlane2(Areg, np);
@@ -186,7 +233,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             }
             SC_TIME(4);  // output phase (C tile reads)
             if (more) {
-                sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev);
+                sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev, dma_now);
                 SC_FWD_ADVANCE();
             }
             SC_TIME(5);  // staging store
@@ -198,7 +245,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         if (z_row) {
             float zz[SC_S];
 #ifndef SC_FWD_PREFETCH
-            sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
+            if constexpr (PREF)
+                read_vector(4 + 2 * (int)(c & 1), p0, z_raw);  // landed long ago: the chunk-start wait covered it
+            else
+                sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
 #endif
             sc_unpack<T, SC_S>(z_raw, rev, zz);
 #pragma unroll
@@ -224,22 +274,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 SC_TIME_EXPORT(cad_debug_timing_fwd)
 
 static_assert(SC_CHUNK == SC_STATE_STEP || SC_CHUNK == 2 * SC_STATE_STEP, "forward chunk = one or two state slots");
-
-// more than 64 KB of dynamic LDS has to be requested per kernel (once)
-#if defined(CAD_EMU)
-#define SC_FWD_BIG_LDS(kern, bytes) (void)0
-#else
-#define SC_FWD_BIG_LDS(kern, bytes)                                                                                  \
-    do {                                                                                                             \
-        static bool done = false;                                                                                    \
-        if ((bytes) > 65536 && !done) {                                                                              \
-            if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != \
-                hipSuccess)                                                                                          \
-                return CAD_ERR_LAUNCH;                                                                                 \
-            done = true;                                                                                             \
-        }                                                                                                            \
-    } while (0)
-#endif
 
 extern "C" int64_t cad_scan_chunk_len(void) { return SC_CHUNK; }
 
@@ -269,10 +303,11 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
                        (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm) % 16) == 0;
     CadProfScope prof(0, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const size_t shmem = (size_t)SC_RING_FWD * 2 * SC_TILE(SC_S) * sizeof(float);
+    const size_t shmem = (size_t)SC_RING_FWD * 2 * SC_TILE(SC_S) * sizeof(float) +
+                         ((SC_FWD_DMA && vec && a->dtype == CAD_BF16 && SC_S == 16) ? PRE_BYTES : 0);
 #define SC_FWD_LAUNCH(T, V)                                                                                         \
     do {                                                                                                            \
-        SC_FWD_BIG_LDS((scan_fwd_kernel<T, V>), shmem);                                                             \
+        SC_BIG_LDS((scan_fwd_kernel<T, V>), shmem);                                                             \
         CAD_LAUNCH((scan_fwd_kernel<T, V>), grid, block, shmem, stream, ks);                                        \
     } while (0)
     if (a->dtype == CAD_F32) {

@@ -60,6 +60,13 @@ class BucketedGradReducer:
                 p.register_post_accumulate_grad_hook(self._hook)
             self.buckets.append(flat)
         self._sizes = [len(g) for g in groups]
+        # (bucket, element offset) of every parameter, for re-attaching a gradient autograd replaced
+        self._slot = {}
+        for bi, grp in enumerate(groups):
+            off = 0
+            for p in grp:
+                self._slot[id(p)] = (bi, off)
+                off += p.numel()
         self._reset_counters()
 
     def _reset_counters(self):
@@ -67,12 +74,10 @@ class BucketedGradReducer:
         self._handles = [None] * len(self.buckets)
 
     def _hook(self, p: torch.nn.Parameter):
-        bi = self._bucket_of[id(p)]
+        bi, off = self._slot[id(p)]
         flat = self.buckets[bi]
         if p.grad.data_ptr() < flat.data_ptr() or p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * 4:
             # autograd replaced .grad (e.g. after zero_grad(set_to_none=True)): copy back into the bucket view
-            off = sum(q.numel() for q in self.params if self._bucket_of[id(q)] == bi and
-                      self.params.index(q) < self.params.index(p))
             view = flat[off:off + p.numel()].view_as(p)
             view.copy_(p.grad)
             p.grad = view
@@ -106,7 +111,11 @@ class BucketedGradReducer:
             self.r.sync_enabled = False
 
         def __exit__(self, *a):
+            # the accumulation micro-steps decremented the per-bucket counters without launching anything: start the
+            # final (synchronising) micro-step from full counters, so that its hooks fire the all-reduces DURING its
+            # backward (overlap) instead of leaving every bucket to finish()
             self.r.sync_enabled = True
+            self.r._pending = list(self.r._sizes)
 
     def no_sync(self):
         """Gradient accumulation micro-steps (accumulate_grad_batches, configs/experiment/hg38/hg38.yaml:17):

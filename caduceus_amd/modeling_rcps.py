@@ -15,7 +15,13 @@ from .mamba import RMSNorm, act_dtype_of, norm_params
 
 
 def _comp_tensor(complement_map: dict) -> Tensor:
-    return torch.tensor(list(OrderedDict(complement_map).values()), dtype=torch.long)
+    """complement_map[i] by token id i.  Built from the SORTED integer keys: a config that went through HF's JSON
+    round trip (to_json_string sorts the string keys lexicographically: '0', '1', '10', '11', '2', ...) must not
+    scramble the map (the reference relies on dict order, modeling_rcps.py:32-35, and on the checkpoint overwriting it)."""
+    keys = sorted(int(k) for k in complement_map)
+    assert keys == list(range(len(keys))), "complement_map must cover token ids 0 .. V-1"
+    by_int = {int(k): int(v) for k, v in complement_map.items()}
+    return torch.tensor([by_int[k] for k in keys], dtype=torch.long)
 
 
 class RCPSEmbedding(nn.Module):

@@ -44,6 +44,14 @@ class _Embed(torch.autograd.Function):
         V, D, n_strands, wdt = ctx.meta
         dout = dout.contiguous()
         dw = torch.zeros((V, D), dtype=torch.float32, device=dout.device)
+        if V * D * 4 > 64 * 1024:
+            # the kernel keeps the whole (V, D) gradient in LDS (DNA vocabularies: 16 x D); larger vocabularies
+            # (CaduceusConfig's default vocab_size is 50277) scatter-add through the allocator-owning framework instead
+            flat = ids.reshape(-1)
+            dw.index_add_(0, flat, dout[0].reshape(-1, D).float())
+            if n_strands == 2:
+                dw.index_add_(0, comp[flat], dout[1].reshape(-1, D).float())
+            return None, dw.to(wdt), None, None, None
         stream = L.stream_and_check(ids, comp, dout, dw)
         B, Lq = ids.shape
         a = L.EmbedBwdArgs(L.ptr(ids), L.ptr(comp), L.ptr(dout), L.ptr(dw), B, Lq, D, V, n_strands,

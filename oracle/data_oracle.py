@@ -51,13 +51,14 @@ def mlm_threshold(p: float) -> int:
 
 
 def tokenize_mlm(seqs, L, rc_flags=None, mlm_probability=0.15, seed=0, offset=0, mlm=True, vocab=12, row_ids=None):
-    """seqs: list of str (each <= L).  Returns (input_ids, labels) int64 (B, L); labels None when mlm is False."""
+    """seqs: list of str (longer than L: the first L tokens are kept).  Returns (input_ids, labels) int64 (B, L); labels None when mlm is False."""
     B = len(seqs)
     ids = np.full((B, L), PAD, dtype=np.int64)
     valid = np.zeros((B, L), dtype=bool)
     for b, s in enumerate(seqs):
         if rc_flags is not None and rc_flags[b]:
             s = reverse_complement(s)
+        s = s[:L]  # tokenizer(truncation=True), default truncation_side="right" (hg38_dataset.py:190-200), after the RC
         t = np.asarray(tokenize(s), dtype=np.int64)
         t[t == N_ID] = PAD
         if len(s):

@@ -118,6 +118,25 @@ def test_tokenize_mlm_kernel_bit_exact(backend, B, L, ragged, mlm):
         assert labels is None
 
 
+def test_tokenize_truncates_on_the_right(backend):
+    """pad_max_length < max_length: the reference tokenizer keeps the FIRST pad_max_length tokens (truncation=True,
+    truncation_side "right", hg38_dataset.py:190-200), after the reverse complement."""
+    _, dev = backend
+    rng = np.random.default_rng(77)
+    L = 8
+    lens = np.array([16, 8, 5, 12])
+    raw, seqs = _rows(4, 20, rng, lens)
+    raw[0, :16] = np.frombuffer(b"AAAACCCCGGGGTTTT", dtype=np.uint8)
+    seqs[0] = "AAAACCCCGGGGTTTT"
+    rc = np.array([0, 1, 0, 1], dtype=np.uint8)
+    ids, _ = cdata.tokenize_mlm(torch.from_numpy(raw).to(dev), torch.from_numpy(lens.astype(np.int64)).to(dev),
+                                torch.from_numpy(rc).to(dev), L, mlm=False)
+    want, _ = do.tokenize_mlm(seqs, L, rc_flags=rc, mlm=False)
+    assert np.array_equal(ids.cpu().numpy(), want)
+    assert ids[0].tolist() == [7, 7, 7, 7, 8, 8, 8, 8]  # AAAACCCC, not GGGGTTTT
+    assert ids[3].tolist() == do.tokenize(do.reverse_complement(seqs[3])[:L])
+
+
 def test_tokenize_mlm_row_streams(backend):
     """row_ids select the random stream of a row: bit-exact vs the oracle, and a sample's corruption does not depend on
     which batch row it occupies."""

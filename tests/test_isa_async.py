@@ -43,7 +43,9 @@ def _walk_to_wait(lines, labels, start, pending, where):
             in_asm = False
         elif not line or line.startswith((";", ".")) and not re.match(r"^\.LBB\d+_\d+:", line) or line.endswith(":"):
             pass
-        elif in_asm and line.startswith("s_waitcnt vmcnt(0)"):
+        elif in_asm and line.startswith(("s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(6)")):
+            # vmcnt(6): the counted form of the pair-step in which SC_NDMA = 6 LDS-DMA operations were issued BEHIND the
+            # tile loads (scan_common.h: sc_async_wait_keep) -- the tile loads are complete, only the DMA stays in flight
             return steps
         elif in_asm and line.startswith("global_load_dword"):
             assert not (pending & _mentioned(line.split(None, 2)[2])), f"{where}: `{line}` uses an in-flight register as address"
@@ -76,8 +78,15 @@ def test_async_prefetch_registers_untouched(tmp_path, src):
         body = lines[a:b]
         kernel = body[0].split(":")[0]
         labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
-        n_waits += sum(1 for i, l in enumerate(body) if l.strip().startswith("s_waitcnt vmcnt(0)")
-                       and body[i - 1].strip().startswith(";;#ASMSTART"))
+        in_asm = False
+        for l in body:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and t.startswith("s_waitcnt vmcnt(0)"):
+                n_waits += 1
         for i, l in enumerate(body):
             t = l.strip()
             if t.startswith("global_load_dword") and body[i - 1].strip().startswith(";;#ASMSTART"):

@@ -393,3 +393,24 @@ def test_lm_head_loss_is_deterministic(backend):
     logits = ops.lm_head(hidden, w, comp, None, 4)[0]
     ref = F.cross_entropy(logits.reshape(-1, V).cpu().double(), labels.reshape(-1).cpu(), ignore_index=4)
     torch.testing.assert_close(losses[0].cpu().double(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_strands", [1, 2])
+def test_embed_large_vocabulary_backward(backend, n_strands):
+    """V * D * 4 > 64 KB (e.g. CaduceusConfig's default vocab_size): the LDS-resident gradient kernel does not apply and
+    the op scatter-adds instead; forward stays on the gather kernel."""
+    name, dev = backend
+    g = torch.Generator().manual_seed(9)
+    V, D, B, L = 4096, 64, 2, 50
+    w = torch.randn(V, D, generator=g)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    comp = torch.randperm(V, generator=g)
+    wd = leaf(w, dev)
+    out = ops.embed(ids.to(dev), wd, comp.to(dev) if n_strands == 2 else None, n_strands)
+    up = torch.randn(out.shape, generator=g)
+    (out * up.to(dev)).sum().backward()
+    wr = leaf(w, "cpu")
+    ref = [wr[ids]] + ([wr[comp[ids]]] if n_strands == 2 else [])
+    (torch.stack(ref) * up).sum().backward()
+    assert torch.equal(out.detach().cpu(), torch.stack(ref).detach())
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-5)
