@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CADUCEUS_AMD_LIB") or os.path.join(HERE, "libcaduceus_hip.so")
 
 CAD_F32, CAD_BF16 = 0, 1
-PROF_KINDS = ("scan_fwd", "scan_bwd", "conv_fwd", "conv_bwd", "add_norm_fwd", "add_norm_bwd", "embed", "lm_head")
+PROF_KINDS = ("scan_fwd", "scan_bwd", "conv_fwd", "conv_bwd", "add_norm_fwd", "add_norm_bwd", "embed", "lm_head", "proj")
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -87,6 +87,11 @@ class MlmArgs(C.Structure):
                 ("pad_id", _i), ("mask_id", _i), ("unk_id", _i), ("n_id", _i), ("vocab", _i), ("base_ids", _i * 4), ("row_ids", _p)]
 
 
+class ProjArgs(C.Structure):
+    _fields_ = [("W", _p), ("X", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
+                ("ldo", _i64)]
+
+
 class LmHeadArgs(C.Structure):
     _fields_ = [("hidden", _p), ("weight", _p), ("comp", _p), ("labels", _p), ("logits", _p), ("loss_sum", _p),
                 ("count", _p), ("rows", _i64), ("D", _i), ("V", _i), ("n_strands", _i), ("ignore_index", _i64),
@@ -121,6 +126,8 @@ SYMBOLS = {
     "cad_scan_tm_block_len": (_i64, []),
     "cad_scan_tm_state_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_scan_tm_scratch_floats": (_i64, [_i, _i64, _i64, _i]),
+    "cad_proj_wxT": (_i, [C.POINTER(ProjArgs), _p]),
+    "cad_proj_supported": (_i, [_i]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_lm_head_partials": (_i64, [_i64]),
     "cad_tokenize_mlm": (_i, [C.POINTER(MlmArgs), _p]),

@@ -277,6 +277,29 @@ __device__ __forceinline__ uint32_t cad_pack_bf16x2_safe(float lo, float hi) {
 #endif
 }
 
+// ---- LDS-DMA: asynchronous 16-byte-per-lane copy global -> LDS (no VGPR involved) ----------------------------------
+// global_load_lds_dwordx4: lane l's 16 bytes, read from its own global address, land at (wave-uniform LDS base in M0)
+// + 16 l.  Tracked by vmcnt like any load: the issuing wave waits vmcnt before its ds_read (and a barrier before another
+// wave's).  A swizzled LDS image is obtained by permuting the per-lane SOURCE addresses; the destination is always linear.
+__device__ __forceinline__ uint32_t cad_lds_off(const void* p) {  // byte offset of an LDS object inside the LDS aperture
+#ifdef CAD_EMU
+    return (uint32_t)((const char*)p - emu::dyn_smem());
+#else
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+#endif
+}
+__device__ __forceinline__ void cad_glds16(const void* gsrc /* per lane */, uint32_t lds_base /* wave-uniform, SGPR */) {
+#ifdef CAD_EMU
+    std::memcpy(emu::dyn_smem() + lds_base + 16 * emu::lane_id(), gsrc, 16);
+#else
+    uint32_t keep;  // M0 holds the LDS base of the DMA; it is compiler-reserved, so save / restore it in the same statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+#endif
+}
+
 // wave-uniform "any lane" vote
 __device__ __forceinline__ bool cad_wave_any(bool p) {
 #ifdef CAD_EMU

@@ -18,6 +18,10 @@
 // second, purely streaming pass.
 #include "scan_common.h"
 
+#ifndef SC_PRE_WAIT
+#define SC_PRE_WAIT 0   // 1: counted wait at the chunk start (leaves the most recent stores in flight)
+#endif
+
 namespace {
 
 struct ScanBwdSets {
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         selA[2] = (lane & 3) == 2 ? one : 0u, selA[3] = (lane & 3) == 3 ? one : 0u;
     }
     const int wave = cad_uniform(threadIdx.x >> 6);
+    sc_static_priority(wave, SC_W);
     const int64_t sb = blockIdx.y;
     const int e_raw = blockIdx.x * SC_W + wave;
     const bool act = e_raw < a.E;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
         if constexpr (PREF) {
             // this chunk's vectors were fetched into LDS one chunk ago
-            sc_wait_all_loads();
+            sc_wait_loads<SC_PRE_WAIT ? 3 : 0>();
             const char* slot = pre + wave * (64 * 16) + lane * 16;
             const bool in = p0 < L;
             typedef ScVec<T, SC_S> V;
@@ -206,10 +211,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 if (a.gate_fix_list) {
                     // out / z cannot recover y where the gate is exactly 0 (out == 0 there): remember the chunk, the
                     // fix-up launch (cad_scan_bwd_gate_fix) recomputes y for it and adds dout * y / 2 to dz
-                    bool z0 = false;
+                    int z0 = 0;  // (bitwise, not short-circuit: no branch per item)
 #pragma unroll
-                    for (int i = 0; i < SC_S; ++i) z0 = z0 || (zz[i] == 0.f && p0 + i < L);
-                    if (cad_wave_any(z0 && act) && lane == 0) {
+                    for (int i = 0; i < SC_S; ++i) z0 |= (int)(zz[i] == 0.f) & (int)(p0 + i < L);
+                    if (cad_wave_any(z0 != 0 && act) && lane == 0) {
                         const int slot = atomicAdd(a.gate_fix_count, 1);
                         a.gate_fix_list[slot] = (int64_t)e | ((int64_t)sb << 20) | ((int64_t)c << 40);
                     }
@@ -223,21 +228,30 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         for (int i = 0; i < SC_S; ++i) oo[i] += o2[i];
                     }
                 }
+                // (the wave-uniform `o_row` test is hoisted out of the item loop: inside it the compiler keeps one
+                // branch per item and cannot schedule across them)
+                if (o_row) {
 #pragma unroll
-                for (int i = 0; i < SC_S; ++i) {
-                    const float sg = cad_sigmoid(zz[i]);
-                    if (o_row) {
-                        const float ys = (zz[i] == 0.f) ? 0.f : oo[i] * cad_rcp(zz[i]);
+                    for (int i = 0; i < SC_S; ++i) {
+                        const float sg = cad_sigmoid(zz[i]);
+                        const float yq = oo[i] * cad_rcp(zz[i]);
+                        const float ys = (zz[i] == 0.f) ? 0.f : yq;
                         dzv[i] = dy[i] * ys * (1.f + zz[i] * (1.f - sg));
+                        dy[i] *= zz[i] * sg;
                     }
-                    dy[i] *= zz[i] * sg;
+                    if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
                 }
-                if (o_row && act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
             }
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
-                const bool ok = p0 + i < L;
-                const float dti = ok ? cad_softplus(dt[i] + bias) : 0.f;
+                // softplus is evaluated for every lane and masked afterwards (a select, not a branch around the
+                // transcendental sequence); on the vector path all items of a lane are in or out of range together
+                const bool ok = VEC ? (p0 < L) : (p0 + i < L);
+                const float sp = cad_softplus(dt[i] + bias);
+                const float dti = ok ? sp : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
                 ddt[i] = 0.f;
                 gBs[i] = 0.f;
@@ -254,6 +268,28 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c - 1) * NP + lane) * 2;
             hin_next = f2(stp[0], stp[1]);
         }
+        // per-item outputs of this chunk (all states folded in): u / delta from the raw vectors loaded at the chunk's start.
+        // With the LDS-DMA prefetch nothing overwrites those registers, so it runs once BEHIND the pair loop (inside the
+        // loop the compiler if-converts it and evaluates its transcendentals in every pair-step).
+        auto chunk_epilogue = [&]() {
+            float uu[SC_S], dl[SC_S], du[SC_S];
+            sc_unpack<T, SC_S>(u_raw, rev, uu);
+            sc_unpack<T, SC_S>(d_raw, rev, dl);
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                const float xraw = dl[i] + bias;
+                const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
+                const float dyi = dy2[i >> 1][i & 1];
+                const bool ok = VEC ? (p0 < L) : (p0 + i < L);
+                du[i] = dd[i][0] * gBs[i] + dyi * Dv;
+                ddt[i] = ok ? (ddt[i] + uu[i] * gBs[i]) * sg : 0.f;
+                dbacc += ddt[i];
+            }
+            if (act) {
+                sc_store<T, SC_S, VEC>(du_row, p0, L, rev, du);
+                sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
+            }
+        };
         SC_TIME(1);  // chunk prologue: unpack, gate, softplus
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
@@ -360,25 +396,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             SC_TIME(7);  // gradient loop + slab writes
             dAp = wave_sum2_dpp(dAp);
             if (lane == np) dAacc = dAacc + dAp * f2(keep);
-            if (np == NP - 1) {
-                // per-item outputs of this chunk (all states folded in): u / delta from the raw vectors loaded at the
-                // chunk's start; done before the barrier so that the prefetch below may overwrite those registers
-                float uu[SC_S], dl[SC_S], du[SC_S];
-                sc_unpack<T, SC_S>(u_raw, rev, uu);
-                sc_unpack<T, SC_S>(d_raw, rev, dl);
-#pragma unroll
-                for (int i = 0; i < SC_S; ++i) {
-                    const float xraw = dl[i] + bias;
-                    const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
-                    const float dyi = dy2[i >> 1][i & 1];
-                    du[i] = dd[i][0] * gBs[i] + dyi * Dv;
-                    ddt[i] = (p0 + i < L) ? (ddt[i] + uu[i] * gBs[i]) * sg : 0.f;
-                    dbacc += ddt[i];
-                }
-                if (act) {
-                    sc_store<T, SC_S, VEC>(du_row, p0, L, rev, du);
-                    sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
-                }
+            if constexpr (!PREF) {
+                // (register prefetch: the next chunk's vectors overwrite u_raw / d_raw behind this pair's barrier)
+                if (np == NP - 1) chunk_epilogue();
             }
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
             if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
@@ -480,6 +500,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (SC_SLAB_BUFS == 1) __syncthreads();  // the slab is rewritten by the next pair
             SC_TIME(11);  // next chunk's loads issued + flush
         }
+        if constexpr (PREF) chunk_epilogue();
     }
     if (a.dh0 && act && lane < NP) {  // gradient w.r.t. the state entering the row
         float* gp = a.dh0 + ((int64_t)e * SB + sb) * N + 2 * lane;

@@ -299,10 +299,60 @@ __device__ __forceinline__ void sc_load_raw(const T* row, int64_t p0, int64_t L,
         }
     }
 }
+// v_cndmask with a wave-uniform 64-bit lane mask in SGPRs.  Written in asm: a C++ select between two ELEMENTS of a vector
+// (`rev ? v[S-1-j] : v[j]`) is canonicalised into a dynamic index = a chain of S-1 compares + selects per element
+// (measured in the chunk epilogue of the backward: 119 v_cndmask + 56 s_cmp/s_cselect for two 8-item stores).
+__device__ __forceinline__ uint32_t sc_sel(uint32_t if0, uint32_t if1, uint64_t mask) {
+#ifdef CAD_EMU
+    return mask ? if1 : if0;
+#else
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+    return r;
+#endif
+}
+__device__ __forceinline__ uint64_t sc_rev_mask(int rev) {  // all lanes set <=> right-to-left row (wave-uniform)
+#ifdef CAD_EMU
+    return rev ? ~0ull : 0ull;
+#else
+    const uint32_t r = __builtin_amdgcn_readfirstlane(rev ? ~0u : 0u);
+    return ((uint64_t)r << 32) | r;
+#endif
+}
+__device__ __forceinline__ uint32_t sc_rot(uint32_t x, uint32_t rot) {  // rotate right by rot bits (0 or 16 here)
+#ifdef CAD_EMU
+    return rot ? ((x >> rot) | (x << (32 - rot))) : x;
+#else
+    return __builtin_amdgcn_alignbit(x, x, rot);
+#endif
+}
+
 template <typename T, int S>
 __device__ __forceinline__ void sc_unpack(const ScVec<T, S>& raw, int rev, float* out) {
+    if constexpr (sizeof(T) == 2 && S % 2 == 0) {
+        // bf16: work on the raw dwords -- logical item j is physical element S-1-j on a right-to-left row, i.e. the
+        // dword order is reversed and the halves of every dword swap: one select + one rotate per dword
+        constexpr int NW = S / 2;
+#ifdef CAD_EMU
+        struct W { uint32_t w[NW]; };
+        const W ww = __builtin_bit_cast(W, raw);
+        const uint32_t* w = ww.w;
+#else
+        typedef uint32_t uw __attribute__((ext_vector_type(NW)));  // stays in registers (an array may go to scratch)
+        const uw w = __builtin_bit_cast(uw, raw);
+#endif
+        const uint64_t rmask = sc_rev_mask(rev);
+        const uint32_t rot = rev ? 16u : 0u;
 #pragma unroll
-    for (int j = 0; j < S; ++j) out[j] = to_f32(raw.v[rev ? (S - 1 - j) : j]);
+        for (int q = 0; q < NW; ++q) {
+            const uint32_t x = sc_rot(sc_sel(w[q], w[NW - 1 - q], rmask), rot);
+            out[2 * q] = cad_bits2f(x << 16);
+            out[2 * q + 1] = cad_bits2f(x & 0xFFFF0000u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < S; ++j) out[j] = to_f32(raw.v[rev ? (S - 1 - j) : j]);
+    }
 }
 template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_load(const T* row, int64_t p0, int64_t L, int rev, float* out) {
@@ -312,7 +362,25 @@ __device__ __forceinline__ void sc_load(const T* row, int64_t p0, int64_t L, int
 }
 template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev, const float* v) {
-    if constexpr (VEC) {
+    if constexpr (VEC && sizeof(T) == 2 && (S == 8 || S == 16)) {
+        // bf16: convert in logical order, then reverse on the packed dwords (see sc_unpack)
+        if (p0 < L) {
+            const int64_t l0 = rev ? (L - p0 - S) : p0;
+            constexpr int NW = S / 2;
+            uint32_t pk[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) pk[q] = cad_pack_bf16x2(v[2 * q], v[2 * q + 1]);
+            const uint64_t rmask = sc_rev_mask(rev);
+            const uint32_t rot = rev ? 16u : 0u;
+#pragma unroll
+            for (int q = 0; q < NW; q += 4) {
+                u32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = sc_rot(sc_sel(pk[q + t], pk[NW - 1 - q - t], rmask), rot);
+                *(u32x4*)(row + l0 + 2 * q) = o;
+            }
+        }
+    } else if constexpr (VEC) {
         if (p0 < L) {
             const int64_t l0 = rev ? (L - p0 - S) : p0;
             float m[S];  // memory order
@@ -433,27 +501,30 @@ static_assert(SC_NDMA == 6, "the immediate of s_waitcnt vmcnt(6) above");
 // global address straight into LDS at (wave-uniform base) + 16 * lane without touching a VGPR, so the NEXT chunk's
 // vectors are fetched one whole chunk ahead into wave-private LDS slots and read back with ds_read_b128 when needed.
 // Completion is tracked by vmcnt like any load (the issuing wave waits vmcnt(0) before its ds_read).
-__device__ __forceinline__ uint32_t sc_lds_off(const void* p) {  // byte offset of an LDS object inside the LDS aperture
-#ifdef CAD_EMU
-    return (uint32_t)((const char*)p - emu::dyn_smem());
-#else
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-#endif
-}
-__device__ __forceinline__ void sc_glds16(const void* gsrc /* per lane */, uint32_t lds_base /* wave-uniform, SGPR */) {
-#ifdef CAD_EMU
-    std::memcpy(emu::dyn_smem() + lds_base + 16 * emu::lane_id(), gsrc, 16);
-#else
-    uint32_t keep;  // M0 holds the LDS base of the DMA; it is compiler-reserved, so save / restore it in the same statement
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base)
-                 : "memory");
-#endif
-}
-__device__ __forceinline__ void sc_wait_all_loads() {
+__device__ __forceinline__ uint32_t sc_lds_off(const void* p) { return cad_lds_off(p); }
+__device__ __forceinline__ void sc_glds16(const void* gsrc, uint32_t lds_base) { cad_glds16(gsrc, lds_base); }
+// Wait until at most KEEP vector-memory operations are outstanding.  vmcnt retires in issue order on gfx9-class hardware
+// (loads, LDS-DMA and stores alike -- the compiler's own counted waits rely on it), so with KEEP = the number of stores
+// issued after the prefetch that may still be waiting for their write acknowledgement, the prefetch is known to have
+// landed while those (recent) stores stay in flight.
+template <int KEEP>
+__device__ __forceinline__ void sc_wait_loads() {
 #ifndef CAD_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+#endif
+}
+// Static priority for the second half of a workgroup's waves (MI355X: of the two waves a 512-thread workgroup places on
+// each SIMD, the later-dispatched one loses VALU arbitration; measured here: waves 4-7 spend 1.2-2.3x the cycles of
+// waves 0-3 in the DPP / packed-FMA phases, profiles/r02_phase_timing_dma_prefetch.txt, while waves 0-3 -- which also do
+// the tile staging -- idle at the barrier).
+#ifndef SC_PRIO
+#define SC_PRIO 0
+#endif
+__device__ __forceinline__ void sc_static_priority(int wave, int nwaves) {
+#if SC_PRIO == 1 && !defined(CAD_EMU)
+    if (wave >= nwaves / 2) __builtin_amdgcn_s_setprio(1);  // wave is wave-uniform (readfirstlane): a scalar branch
+#elif SC_PRIO == 2 && !defined(CAD_EMU)
+    if (wave < nwaves / 2) __builtin_amdgcn_s_setprio(1);   // A/B: the staging half instead
 #endif
 }
 

@@ -2,6 +2,10 @@
 // See scan_common.h for the decomposition.
 #include "scan_common.h"
 
+#ifndef SC_PRE_WAIT
+#define SC_PRE_WAIT 0   // 1: counted wait at the chunk start (leaves the most recent stores in flight)
+#endif
+
 namespace {
 
 struct ScanFwdSets {
@@ -37,6 +41,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const cad_scan_args& a = sets.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
+    sc_static_priority(wave, SC_W);
     const int64_t sb = blockIdx.y;
     const int e_raw = blockIdx.x * SC_W + wave;
     const bool act = e_raw < a.E;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         f32x2 dd[SC_S];  // (dt, dt * u)
 #ifndef SC_FWD_PREFETCH
         if constexpr (PREF) {
-            sc_wait_all_loads();  // this chunk's vectors were fetched into LDS one chunk ago
+            sc_wait_loads<SC_PRE_WAIT ? 2 : 0>();  // this chunk's vectors were fetched into LDS one chunk ago
             read_vector(0, p0, u_raw);
             read_vector(2, p0, d_raw);
         } else if (c > 0) {
@@ -163,7 +168,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #endif
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
-            const float dti = (p0 + i < L) ? cad_softplus(dt[i] + bias) : 0.f;
+            // evaluated for every lane, masked afterwards: a select instead of a branch around the transcendentals of every
+            // item (on the vector path a lane's items are in or out of range together)
+            const float sp = cad_softplus(dt[i] + bias);
+            const float dti = (VEC ? (p0 < L) : (p0 + i < L)) ? sp : 0.f;
             y2[i] = f2(Dv * du[i], 0.f);
             dd[i] = f2(dti, dti * du[i]);
         }

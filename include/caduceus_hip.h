@@ -300,6 +300,26 @@ int64_t cad_scan_tm_state_floats(int E, int64_t SB, int64_t L, int N);
 int64_t cad_scan_tm_scratch_floats(int E, int64_t SB, int64_t L, int N);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Dense projections of the mixer on the matrix cores (bf16 MFMA, fp32 accumulation).   Replace the `in_proj` /
+ * `out_proj` nn.Linear calls inside mamba_ssm.Mamba.forward -> mamba_inner_fn reached from modeling_caduceus.py:128,130
+ * (weights tied across directions at :114-118), in the channel-major / token-major layouts of this library.
+ * cad_proj_wxT:  out (M, T) channel-major = W (M, K) . X (T, K)^T     -- in_proj (W = in_proj.weight, X = normed tokens)
+ *                                                                      and d(y) = W_out^T . dout^T of the backward.
+ * All operands bf16, row strides ld* in ELEMENTS (multiples of 8); K must satisfy cad_proj_supported(K); any M, T.
+ * The per-token result does not depend on the token's position (fixed reduction order): t-frame strands / directions
+ * get bit-identical projections. */
+typedef struct {
+    const void* W;
+    const void* X;
+    void* out;
+    int64_t T;
+    int M, K;
+    int64_t ldw, ldx, ldo;
+} cad_proj_args;
+int cad_proj_wxT(const cad_proj_args* a, void* stream);
+int cad_proj_supported(int K);
+
+/* ---------------------------------------------------------------------------------------------------------
  * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()
  * (modeling_caduceus.py:475) and cross_entropy(ignore_index) (modeling_caduceus.py:279-283,
  * src/tasks/metrics.py:181-184).  t-frame:  logits[b,l,v] = <W[v], t1[b,l]> + <W[comp[v]], t2[b,l]>.
@@ -375,8 +395,8 @@ int cad_fasta_fetch(void* handle, int64_t seq, int64_t start, int64_t end, uint8
 
 /* ---------------------------------------------------------------------------------------------------------
  * Opt-in kernel timer (HIP events on the launch stream) used by bench.py for the roofline line.
- * kind: 0 scan_fwd, 1 scan_bwd, 2 conv_fwd, 3 conv_bwd, 4 add_norm_fwd, 5 add_norm_bwd, 6 embed, 7 lm_head. */
-#define CAD_PROF_KINDS 8
+ * kind: 0 scan_fwd, 1 scan_bwd, 2 conv_fwd, 3 conv_bwd, 4 add_norm_fwd, 5 add_norm_bwd, 6 embed, 7 lm_head, 8 proj. */
+#define CAD_PROF_KINDS 9
 int cad_prof_enable(int on);
 int cad_prof_reset(void);
 /* Synchronises the recorded events.  Outputs total milliseconds and number of launches of that kind. */

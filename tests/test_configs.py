@@ -1,0 +1,192 @@
+"""BASELINE.json's configurations at their stated shapes, on the MI355X, through the C-ABI:
+configs[0] PS d128 n4 L1024 (fp32, every gradient against the oracle), configs[1] Ph d256 n16 L1024 bf16 (against the fp32
+oracle at the reference's bf16 tolerance), configs[2] the full 16-layer d256 model at seqlen 131072 (RC-equivariance of
+the training step: bit-exact logits, finite gradients that are themselves RC-related), and the gradient all-reduce of
+configs[3] through RCCL on one GPU."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _real_library():
+    from caduceus_amd import _lib
+    _lib.use_library_for_testing(None)
+    assert torch.cuda.is_available() and _lib.is_device_build()
+    yield
+
+
+def _oracle_cfg(n_layer, rcps):
+    return dict(rcps=rcps, fused_add_norm=True, rms_norm=True, norm_epsilon=1e-5, n_layer=n_layer, bidirectional=True,
+                bidirectional_strategy="add")
+
+
+def _oracle_step(model, cfg, ids, labels):
+    """fp32 forward + backward of the CPU oracle (C/OpenMP scan) on a detached copy of the model's parameters."""
+    from oracle import oracle_model as om
+    from oracle import oracle_ops
+    sd, leaves = {}, {}
+    for k, v in model.state_dict().items():
+        if not v.is_floating_point():
+            sd[k] = v.cpu()
+            continue
+        key = (v.data_ptr(), tuple(v.shape))  # tied tensors (embedding / head, in_proj / out_proj of the two directions,
+        if key not in leaves:                  # modeling_caduceus.py:114-118) are ONE leaf, as in the model
+            leaves[key] = v.detach().cpu().clone().requires_grad_(True)
+        sd[k] = leaves[key]
+    om.set_scan_backend(oracle_ops.selective_scan_c)
+    try:
+        out = om.masked_lm_forward(sd, ids.cpu(), cfg, labels=labels.cpu(), ignore_index=4)
+        out["loss"].backward()
+    finally:
+        om.set_scan_backend(None)
+    return out, sd
+
+
+def test_config0_ps_d128_n4_L1024_fp32_vs_oracle():
+    """configs[0]: Caduceus-PS d_model=128 n_layer=4 seqlen=1024 batch=1 -- logits, loss and EVERY parameter gradient."""
+    from bench import make_config, synthetic_batch
+    from caduceus_amd import CaduceusForMaskedLM
+    torch.manual_seed(2222)
+    model = CaduceusForMaskedLM(make_config(128, 4)).to(DEV).train()
+    ids, labels = synthetic_batch(torch.Generator().manual_seed(5), 1, 1024, DEV)
+    out = model(ids, labels=labels)
+    out.loss.backward()
+    ref, sd = _oracle_step(model, _oracle_cfg(4, True), ids, labels)
+    torch.testing.assert_close(out.logits.cpu(), ref["logits"], rtol=6e-4, atol=2e-3)
+    torch.testing.assert_close(out.loss.cpu(), ref["loss"].detach(), rtol=6e-4, atol=2e-3)
+    named = dict(model.named_parameters())
+    checked = 0
+    for k, p in named.items():
+        want = sd[k].grad
+        assert want is not None and p.grad is not None, k
+        scale = max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=6e-4, atol=2e-3 * scale, msg=lambda m, k=k: f"{k}: {m}")
+        checked += 1
+    assert checked > 40
+
+
+def test_config1_ph_d256_n16_L1024_bf16_vs_oracle():
+    """configs[1]: Caduceus-Ph d_model=256 n_layer=16 seqlen=1024, bf16 autocast, RC augmentation on (half of the rows
+    are reverse complements) -- against the fp32 oracle at the reference's bf16 tolerance class."""
+    from bench import COMP, make_config, synthetic_batch
+    from caduceus_amd import CaduceusForMaskedLM
+    torch.manual_seed(2222)
+    model = CaduceusForMaskedLM(make_config(256, 16, rcps=False)).to(DEV).train()
+    ids, labels = synthetic_batch(torch.Generator().manual_seed(6), 4, 1024, DEV)
+    comp = torch.tensor([COMP.get(i, i) for i in range(16)], device=DEV)
+    ids[2:], labels[2:] = comp[ids[2:].flip(-1)], comp[labels[2:].flip(-1)]  # RC-aug rows
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(ids, labels=labels)
+    out.loss.backward()
+    ref, sd = _oracle_step(model, _oracle_cfg(16, False), ids, labels)
+    rel = float((out.logits.cpu() - ref["logits"]).norm() / ref["logits"].norm())
+    assert rel < 3e-2, rel
+    assert abs(float(out.loss) - float(ref["loss"])) < 0.05 * max(1.0, float(ref["loss"]))
+    named = dict(model.named_parameters())
+    worst = 1.0
+    for k, p in named.items():
+        want = sd[k].grad
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        if float(want.norm()) > 1e-6:
+            cos = float(F.cosine_similarity(p.grad.float().cpu().flatten(), want.flatten(), dim=0))
+            worst = min(worst, cos)
+            assert cos > 0.97, (k, cos)
+    assert worst > 0.97
+
+
+def test_config2_full_model_16_layers_L131072():
+    """configs[2]: the headline model itself -- PS d_model=256 n_layer=16 seqlen=131072, bf16 autocast, one training
+    forward + backward.  Logits are RC-equivariant bit-exactly; gradients are finite, and the gradient of the RC input
+    equals the gradient of the input (the loss is RC-invariant) to summation-order rounding."""
+    from bench import COMP, make_config, synthetic_batch
+    from caduceus_amd import CaduceusForMaskedLM
+    torch.manual_seed(1)
+    model = CaduceusForMaskedLM(make_config(256, 16)).to(DEV).train()
+    L = 131072
+    ids, labels = synthetic_batch(torch.Generator().manual_seed(3), 1, L, DEV)
+    comp = torch.tensor([COMP.get(i, i) for i in range(16)], device=DEV)
+    rc = lambda x: comp[x.flip(-1)]
+
+    def run(i, l):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(i, labels=l)
+        out.loss.backward()
+        return out, {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    a, ga = run(ids, labels)
+    b, gb = run(rc(ids), rc(labels))
+    assert torch.isfinite(a.logits).all() and torch.isfinite(a.loss)
+    assert torch.equal(a.logits, b.logits.flip(1)[..., comp])
+    assert abs(float(a.loss) - float(b.loss)) < 1e-4 * abs(float(a.loss))
+    for k in ga:
+        assert torch.isfinite(ga[k]).all(), k
+    # RC-invariant loss => identical parameter gradients up to the order of the bf16 sums
+    for k in ("caduceus.backbone.layers.0.mixer.submodule.mamba_fwd.in_proj.weight",
+              "caduceus.backbone.layers.15.mixer.submodule.mamba_rev.x_proj.weight",
+              "caduceus.backbone.embeddings.word_embeddings.embedding.weight"):
+        cos = float(F.cosine_similarity(ga[k].flatten().float(), gb[k].flatten().float(), dim=0))
+        assert cos > 0.999, (k, cos)
+
+
+def test_config3_bucketed_allreduce_through_rccl():
+    """configs[3]'s only collective, on one GPU: BucketedGradReducer with the forced 1-rank collective launches the
+    bucket all-reduces through RCCL ("nccl" backend) from the post-accumulate hooks; the averaged gradients equal the
+    unsynchronised ones (world size 1), with and without accumulation micro-steps under no_sync()."""
+    import torch.distributed as dist
+    from bench import make_config, synthetic_batch
+    from caduceus_amd import CaduceusForMaskedLM
+    from caduceus_amd.dp import BucketedGradReducer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["CADUCEUS_DP_FORCE_COLLECTIVE"] = "1"
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        import copy
+        torch.manual_seed(4)
+        model = CaduceusForMaskedLM(make_config(64, 2)).to(DEV).train()
+        ref_model = copy.deepcopy(model)  # no hooks: the unsynchronised gradients
+        ids, labels = synthetic_batch(torch.Generator().manual_seed(8), 2, 512, DEV)
+        ref_model(ids, labels=labels).loss.backward()
+        plain = {k: p.grad.detach().clone() for k, p in ref_model.named_parameters()}
+        ref_model.zero_grad(set_to_none=True)
+        (ref_model(ids[:1], labels=labels[:1]).loss * 0.5 + ref_model(ids[1:], labels=labels[1:]).loss * 0.5).backward()
+        plain_acc = {k: p.grad.detach().clone() for k, p in ref_model.named_parameters()}
+        red = BucketedGradReducer(model.parameters(), bucket_bytes=64 << 10)
+        assert red._force and len(red.buckets) > 1
+        red.zero_grad()
+        model(ids, labels=labels).loss.backward()
+        fired = sum(h is not None for h in red._handles)
+        red.finish()
+        torch.cuda.synchronize()
+        assert fired == len(red.buckets)  # every bucket was launched from a hook, i.e. during backward
+        for k, p in model.named_parameters():
+            torch.testing.assert_close(p.grad, plain[k], rtol=0, atol=0)
+        # two accumulation micro-steps, collective only on the second (and again from the hooks: overlap is kept)
+        red.zero_grad()
+        with red.no_sync():
+            (model(ids[:1], labels=labels[:1]).loss * 0.5).backward()
+        assert all(h is None for h in red._handles)
+        (model(ids[1:], labels=labels[1:]).loss * 0.5).backward()
+        assert sum(h is not None for h in red._handles) == len(red.buckets)
+        red.finish()
+        torch.cuda.synchronize()
+        for k, p in model.named_parameters():
+            torch.testing.assert_close(p.grad, plain_acc[k], rtol=1e-5, atol=1e-6)
+    finally:
+        os.environ.pop("CADUCEUS_DP_FORCE_COLLECTIVE", None)
+        if created:
+            dist.destroy_process_group()
