@@ -300,6 +300,17 @@ __device__ __forceinline__ void cad_glds16(const void* gsrc /* per lane */, uint
 #endif
 }
 
+// Point at which every lane of the wave has executed what precedes it.  The hardware runs a wave in lock-step and its LDS
+// queue is in order, so this is only a compiler fence on the device; the host emulator runs lanes as separate fibers and
+// needs a real rendezvous wherever a lane reads LDS written by ANOTHER lane of its wave without a workgroup barrier.
+__device__ __forceinline__ void cad_wave_sync() {
+#ifdef CAD_EMU
+    emu::wave_sync();
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 // wave-uniform "any lane" vote
 __device__ __forceinline__ bool cad_wave_any(bool p) {
 #ifdef CAD_EMU

@@ -76,10 +76,12 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
     const int64_t T = a.T;
     const int M = a.M;
     const int m_wave = blockIdx.y * C::MWG + wave * C::MW;  // first output channel of this wave
-    // token range of this workgroup: whole 64-token blocks, balanced over gridDim.x
+    // token blocks of this workgroup: b = blockIdx.x, + gridDim.x, ...  Interleaved on purpose: the workgroups that run
+    // at the same time then read / write NEIGHBOURING 64-token runs of every row (HBM page locality: a channel-major
+    // output row receives one contiguous multi-KB region from the whole grid instead of 128-byte pieces 4 KB apart)
     const int64_t nblk = (T + C::NT - 1) / C::NT;
-    const int64_t b0 = nblk * blockIdx.x / gridDim.x, b1 = nblk * (blockIdx.x + 1) / gridDim.x;
-    if (b0 >= b1) return;
+    const int64_t b0 = blockIdx.x, bstep = gridDim.x;
+    if (b0 >= nblk) return;
     char* xb[2] = {smem, smem + C::XBUF};
     char* stage = smem + 2 * C::XBUF + wave * C::STAGE;
 
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
     gp_wait_dma();
     __syncthreads();
 
-    for (int64_t b = b0; b < b1; ++b) {
-        const int cur = (int)((b - b0) & 1);
-        if (b + 1 < b1) gp_issue_block<KS>(X, a.ldx, (b + 1) * C::NT, T, xb[cur ^ 1], wave, lane);
+    int cur = 0;
+    for (int64_t b = b0; b < nblk; b += bstep, cur ^= 1) {
+        if (b + bstep < nblk) gp_issue_block<KS>(X, a.ldx, (b + bstep) * C::NT, T, xb[cur ^ 1], wave, lane);
         const char* xt = xb[cur];
 #pragma unroll
         for (int q = 0; q < C::NT / 16; ++q) {  // 16-token sub-blocks
@@ -131,6 +133,10 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
                 *(u32x2*)(stage + (mb * 16 + jl) * C::SSTR + (q * 16 + g * 4) * 2) = pk;
             }
         }
+        // (the staging tile is written as 8-byte and read as 16-byte vectors: distinct types for the compiler's alias
+        // analysis, which may otherwise move the reads above the writes -- on the host emulator build as well)
+        asm volatile("" ::: "memory");
+        cad_wave_sync();
         // the next block has landed (this wave's share; the barrier below publishes everybody's).  Waited for BEFORE this
         // block's stores are issued, so that the wait never sits behind fresh write acknowledgements.
         gp_wait_dma();
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
                 }
             }
         }
-        __syncthreads();  // publishes the next block; orders this block's LDS reads before the DMA that overwrites it
+        __syncthreads();  // publishes the next block; orders this block's LDS reads (X tile, staging tile) before their reuse
     }
 }
 

@@ -20,6 +20,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import ops
 
 
 def _conv_fwd2(x, params, split, dirs):
@@ -119,7 +120,10 @@ class BiMambaMixerFn(torch.autograd.Function):
         E = W_in.shape[0] // 2
         w_in = W_in.to(act)
         w_out = W_out.to(act)
-        xz = torch.mm(w_in, x2d.t()).view(2 * E, SB, Lq)
+        if ops.proj_supported(x2d, Dm):  # bf16: our W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
+            xz = ops.proj_wxT(w_in, x2d).view(2 * E, SB, Lq)
+        else:
+            xz = torch.mm(w_in, x2d.t()).view(2 * E, SB, Lq)
         x, z = xz[:E], xz[E:]
         sets, saved = [], []
         dirs = ((0, 1), (1, 0))
@@ -178,7 +182,10 @@ class BiMambaMixerFn(torch.autograd.Function):
         dirs = ((0, 1), (1, 0))
         dout2d = dout2d.contiguous()
         # tied out_proj: the gradient w.r.t. y_f and y_r is the same tensor, produced channel-major
-        dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)
+        if ops.proj_supported(dout2d, Dm):
+            dy = ops.proj_wxT(w_out.t().contiguous(), dout2d).view(E, SB, Lq)
+        else:
+            dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)
         y_f, y_r = ycat[:E], ycat[E:]
         dW_cat = _wgrad_cm_tm(ycat.view(2 * E, T), dout2d)  # (2E, D): both halves multiply the same tied weight
         dW_out = (dW_cat[:E] + dW_cat[E:]).t()

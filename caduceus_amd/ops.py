@@ -444,3 +444,25 @@ def lm_head(hidden: torch.Tensor, weight: torch.Tensor, comp: Optional[torch.Ten
     """hidden: (S, B, L, D) t-frame -> (fp32 logits (B, L, V), loss or None).  RCPSLMHead + cross_entropy."""
     logits, loss = _LmHead.apply(hidden, weight, comp, labels, ignore_index)
     return logits, (loss if labels is not None else None)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dense projections on the matrix cores (raw ops, no autograd: caduceus_amd/mixer.py schedules their gradients by hand)
+# ------------------------------------------------------------------------------------------------------------------
+def proj_supported(t: torch.Tensor, K: int) -> bool:
+    """The MFMA projection kernels take bf16 operands with a supported reduction length."""
+    return t.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_supported(int(K)))
+
+
+def proj_wxT(W: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (M, T) channel-major = W (M, K) @ X (T, K)^T, bf16 in / fp32 accumulate / bf16 out (cad_proj_wxT)."""
+    M, K = W.shape
+    T = X.shape[0]
+    if X.shape[1] != K or W.stride(1) != 1 or X.stride(1) != 1:
+        raise ValueError("proj_wxT: W (M, K) and X (T, K) with unit inner stride")
+    if out is None:
+        out = torch.empty((M, T), dtype=torch.bfloat16, device=X.device)
+    stream = L.stream_and_check(W, X, out, contiguous=False)
+    a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0))
+    L.check(L.get_lib().cad_proj_wxT(C.byref(a), stream), "cad_proj_wxT")
+    return out

@@ -1,0 +1,48 @@
+"""The hand-written MFMA projection kernels (csrc/gemm.hip) against fp32 matrix products of the same bf16 operands, on
+the host emulator (MFMA / LDS-DMA semantics restated in tests/emu + cad_common.h) and on the GPU."""
+import pytest
+import torch
+
+from caduceus_amd import ops
+
+
+def _bf(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,K,T", [(48, 32, 70), (128, 64, 200), (80, 256, 130), (40, 512, 96), (1024, 128, 64)])
+def test_proj_wxT(backend, M, K, T):
+    name, dev = backend
+    W, X = _bf(M, K, seed=1), _bf(T, K, seed=2)
+    out = ops.proj_wxT(W.to(dev), X.to(dev))
+    ref = W.float() @ X.float().t()
+    assert out.shape == (M, T) and out.dtype == torch.bfloat16
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max()) / 8)
+    # the rounding is that of ONE fp32-accumulated product rounded to bf16
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
+
+
+def test_proj_wxT_is_position_independent(backend):
+    """A token's projection does not depend on where the token sits (block, sub-block, lane): permuting the tokens
+    permutes the output columns bit for bit -- what keeps the t-frame strands / directions bit-identical."""
+    name, dev = backend
+    M, K, T = 96, 64, 333
+    W, X = _bf(M, K, seed=3), _bf(T, K, seed=4)
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(5))
+    a = ops.proj_wxT(W.to(dev), X.to(dev)).cpu()
+    b = ops.proj_wxT(W.to(dev), X[perm].contiguous().to(dev)).cpu()
+    assert torch.equal(a[:, perm], b)
+
+
+def test_proj_wxT_strided_views(backend):
+    name, dev = backend
+    M, K, T = 64, 64, 150
+    Wb, Xb = _bf(M, K + 8, seed=6), _bf(T, K + 16, seed=7)
+    outb = torch.zeros(M, T + 8, dtype=torch.bfloat16, device=dev)
+    W, X = Wb[:, :K].to(dev), Xb[:, :K].to(dev)
+    Wd, Xd = Wb.to(dev)[:, :K], Xb.to(dev)[:, :K]
+    ops.proj_wxT(Wd, Xd, out=outb[:, :T])
+    ref = (Wb[:, :K].float() @ Xb[:, :K].float().t()).to(torch.bfloat16)
+    torch.testing.assert_close(outb[:, :T].float().cpu(), ref.float(), rtol=2e-2, atol=2e-2)
+    assert float(outb[:, T:].abs().max()) == 0.0
