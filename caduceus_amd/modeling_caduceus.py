@@ -348,27 +348,35 @@ class CaduceusForMaskedLM(CaduceusPreTrainedModel):
 
 
 class CaduceusForSequenceClassification(CaduceusPreTrainedModel):
-    """modeling_caduceus.py:495-640 (downstream consumer of the backbone)."""
+    """Sequence-level head on the backbone (reference: modeling_caduceus.py:495-640), computed on
+    the t-frame: the backbone's two strands are separate rows there, so "stack the forward half and the flipped
+    reverse-complement half, pool over the sequence, score both, average" needs no flip, split or stack at all --
+    pooling over positions is order-free for mean / max, and first <-> last simply exchange roles on the second strand.
+    Post-hoc conjoining of a non-RCPS model runs its two inputs as ONE batch.
+
+    Constructor arguments, attribute names (`caduceus`, `score`), the loss selection through `config.problem_type` and the
+    output containers are the reference's.  `pooling_strategy` "first" / "last" return the evident intent (the reference's
+    own code raises TypeError on them: it hands the tensor itself to `moveaxis`, :541-543; recorded in
+    tests/golden/downstream.npz)."""
+
+    POOLINGS = ("mean", "max", "first", "last")
 
     def __init__(self, config: CaduceusConfig, pooling_strategy: str = "mean", conjoin_train: bool = False,
                  conjoin_eval: bool = False, device=None, dtype=None, **kwargs):
         super().__init__(config, **kwargs)
-        if pooling_strategy not in ["mean", "max", "first", "last"]:
+        if pooling_strategy not in self.POOLINGS:
             raise NotImplementedError(f"Pooling strategy `{pooling_strategy}` not implemented.")
         self.pooling_strategy = pooling_strategy
-        factory_kwargs = {"device": device, "dtype": dtype}
         self.num_labels = kwargs.get("num_labels", config.num_labels)
-        self.caduceus = Caduceus(config, **factory_kwargs, **kwargs)
+        self.caduceus = Caduceus(config, device=device, dtype=dtype, **kwargs)
         self.score = nn.Linear(config.d_model, self.num_labels, bias=False)
-        self.conjoin_train = conjoin_train
-        self.conjoin_eval = conjoin_eval
+        self.conjoin_train, self.conjoin_eval = conjoin_train, conjoin_eval
         self.post_init()
         self.init_scorer()
 
     def init_scorer(self, initializer_range=0.02):
-        initializer_range = self.config.initializer_cfg.get("initializer_range", initializer_range) \
-            if self.config.initializer_cfg is not None else initializer_range
-        self.score.weight.data.normal_(std=initializer_range)
+        cfg = self.config.initializer_cfg or {}
+        self.score.weight.data.normal_(std=cfg.get("initializer_range", initializer_range))
 
     def get_input_embeddings(self):
         return self.caduceus.backbone.embeddings.word_embeddings
@@ -378,67 +386,66 @@ class CaduceusForSequenceClassification(CaduceusPreTrainedModel):
             raise NotImplementedError("Setting input embeddings for RCPS LM is not supported.")
         self.caduceus.backbone.embeddings.word_embeddings = value
 
-    def pool_hidden_states(self, hidden_states, sequence_length_dim=1):
-        """Pools hidden states along sequence length dimension."""
-        if self.pooling_strategy == "mean":
+    def pool_hidden_states(self, hidden_states, sequence_length_dim=1, reversed_positions=False):
+        """Pools over the sequence axis.  `reversed_positions`: the rows are stored in the opposite position order to the
+        frame the strategy refers to (second t-frame strand), which only matters for first / last."""
+        how = self.pooling_strategy
+        if how == "mean":
             return hidden_states.mean(dim=sequence_length_dim)
-        if self.pooling_strategy == "max":
+        if how == "max":
             return hidden_states.max(dim=sequence_length_dim).values
-        if self.pooling_strategy == "last":
-            return hidden_states.movedim(sequence_length_dim, 0)[-1, ...]
-        if self.pooling_strategy == "first":
-            return hidden_states.movedim(sequence_length_dim, 0)[0, ...]
+        take_last = (how == "last") != reversed_positions
+        return hidden_states.select(sequence_length_dim, -1 if take_last else 0)
+
+    def _sequence_loss(self, logits, labels):
+        """HF convention (config.problem_type, inferred once from the label dtype / num_labels when unset)."""
+        labels = labels.to(logits.device)
+        if self.config.problem_type is None:
+            if self.num_labels == 1:
+                self.config.problem_type = "regression"
+            elif labels.dtype in (torch.long, torch.int):
+                self.config.problem_type = "single_label_classification"
+            else:
+                self.config.problem_type = "multi_label_classification"
+        kind = self.config.problem_type
+        if kind == "regression":
+            return F.mse_loss(logits.squeeze(), labels.squeeze()) if self.num_labels == 1 else F.mse_loss(logits, labels)
+        if kind == "single_label_classification":
+            return F.cross_entropy(logits.view(-1, self.num_labels), labels.view(-1))
+        if kind == "multi_label_classification":
+            return F.binary_cross_entropy_with_logits(logits, labels)
+        return None
 
     def forward(self, input_ids: torch.LongTensor = None, inputs_embeds: Optional[torch.FloatTensor] = None,
                 labels: Optional[torch.LongTensor] = None, output_hidden_states: Optional[bool] = None,
                 return_dict: Optional[bool] = None) -> Union[Tuple, SequenceClassifierOutput]:
         return_dict = return_dict if return_dict is not None else self._return_dict_default
-        if self.config.rcps:
-            transformer_outputs = self.caduceus(input_ids, inputs_embeds=inputs_embeds,
-                                                output_hidden_states=output_hidden_states, return_dict=return_dict)
-            hs = _first(transformer_outputs)
-            hidden_states = torch.stack([hs[..., :self.config.d_model],
-                                         torch.flip(hs[..., self.config.d_model:], dims=[1, 2])], dim=-1)
-        elif self.conjoin_train or (self.conjoin_eval and not self.training):
-            assert input_ids is not None, "`input_ids` must be provided for conjoining."
-            assert input_ids.ndim == 3, "`input_ids` must be 3D tensor: channels corresponds to forward and rc strands."
-            transformer_outputs = self.caduceus(input_ids[..., 0], inputs_embeds=None,
-                                                output_hidden_states=output_hidden_states, return_dict=return_dict)
-            transformer_outputs_rc = self.caduceus(input_ids[..., 1], inputs_embeds=None,
-                                                   output_hidden_states=output_hidden_states, return_dict=return_dict)
-            hidden_states = torch.stack([_first(transformer_outputs), _first(transformer_outputs_rc)], dim=-1)
+        backbone = self.caduceus.backbone
+        collect = [] if output_hidden_states else None
+        conjoin = (not self.config.rcps) and (self.conjoin_train or (self.conjoin_eval and not self.training))
+        if conjoin:
+            if input_ids is None:
+                raise AssertionError("`input_ids` must be provided for conjoining.")
+            if input_ids.ndim != 3:
+                raise AssertionError("`input_ids` must be 3D tensor: channels corresponds to forward and rc strands.")
+            B = input_ids.shape[0]
+            both = torch.cat([input_ids[..., 0], input_ids[..., 1]], dim=0)  # one pass over (2B, L)
+            t = backbone.forward_tframe(both, None, collect)[0]               # (2B, L, D)
+            pooled = [self.pool_hidden_states(t[:B]), self.pool_hidden_states(t[B:])]
+            if collect is not None:  # the reference reports the hidden states of its first (forward-strand) pass
+                collect = [h[:, :B] for h in collect]
         else:
-            transformer_outputs = self.caduceus(input_ids, inputs_embeds=None,
-                                                output_hidden_states=output_hidden_states, return_dict=return_dict)
-            hidden_states = _first(transformer_outputs)
-        pooled_hidden_states = self.pool_hidden_states(hidden_states)
-        if hidden_states.ndim == 4:
-            wdt = self.score.weight.dtype
-            logits_fwd = self.score(pooled_hidden_states[..., 0].to(wdt))
-            logits_rc = self.score(pooled_hidden_states[..., 1].to(wdt))
-            logits = (logits_fwd + logits_rc) / 2
-        else:
-            logits = self.score(pooled_hidden_states.to(self.score.weight.dtype))
-        loss = None
-        if labels is not None:
-            labels = labels.to(logits.device)
-            if self.config.problem_type is None:
-                if self.num_labels == 1:
-                    self.config.problem_type = "regression"
-                elif self.num_labels > 1 and (labels.dtype == torch.long or labels.dtype == torch.int):
-                    self.config.problem_type = "single_label_classification"
-                else:
-                    self.config.problem_type = "multi_label_classification"
-            if self.config.problem_type == "regression":
-                if self.num_labels == 1:
-                    loss = F.mse_loss(logits.squeeze(), labels.squeeze())
-                else:
-                    loss = F.mse_loss(logits, labels)
-            elif self.config.problem_type == "single_label_classification":
-                loss = F.cross_entropy(logits.view(-1, self.num_labels), labels.view(-1))
-            elif self.config.problem_type == "multi_label_classification":
-                loss = F.binary_cross_entropy_with_logits(logits, labels)
+            t = backbone.forward_tframe(input_ids, inputs_embeds if self.config.rcps else None, collect)
+            pooled = [self.pool_hidden_states(t[0])]
+            if self.config.rcps:  # second strand: positions run the other way in the reference's stacked frame
+                pooled.append(self.pool_hidden_states(t[1], reversed_positions=True))
+        wdt = self.score.weight.dtype
+        logits = self.score(pooled[0].to(wdt))
+        if len(pooled) == 2:
+            logits = (logits + self.score(pooled[1].to(wdt))) / 2
+        loss = self._sequence_loss(logits, labels) if labels is not None else None
+        hidden = tuple(engine.from_tframe(h) for h in collect) if collect is not None else None
         if not return_dict:
-            output = (logits,) + tuple(transformer_outputs[1:]) if isinstance(transformer_outputs, tuple) else (logits,)
-            return ((loss,) + output) if loss is not None else output
-        return SequenceClassifierOutput(loss=loss, logits=logits, hidden_states=transformer_outputs.hidden_states)
+            out = (logits,) + ((hidden,) if hidden is not None else ())
+            return ((loss,) + out) if loss is not None else out
+        return SequenceClassifierOutput(loss=loss, logits=logits, hidden_states=hidden)
