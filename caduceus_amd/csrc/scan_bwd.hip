@@ -711,7 +711,7 @@ extern "C" int cad_scan_bwd_gate_fix(const cad_scan_bwd_args* sets, int nsets, v
         if (!a->gate_fix_list) continue;
         CAD_CHECK_ARG(a->gate_fix_count && a->gate_fix_dz && a->z && a->chunk_state);
         CAD_CHECK_ARG(a->E <= (1 << 20) && a->SB <= (1 << 20));
-        dim3 grid(256), block(256);
+        dim3 grid(32), block(256);  // almost always an empty worklist: keep the dispatch itself small
         if (a->dtype == CAD_F32)
             CAD_LAUNCH((scan_gate_fix_kernel<float>), grid, block, 0, stream, *a);
         else if (a->dtype == CAD_BF16)

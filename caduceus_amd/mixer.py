@@ -88,7 +88,9 @@ def _wgrad_cm_cm(a_cm: torch.Tensor, b_cm: torch.Tensor) -> torch.Tensor:
     if n == 1:
         return torch.mm(a_cm, b_cm.t()).float()
     Kc = T // n
-    return torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_cm.view(-1, n, Kc).permute(1, 2, 0)).float().sum(0)
+    # (sum with fp32 accumulation straight from the bf16 partial products: no separate up-cast launch)
+    return torch.sum(torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_cm.view(-1, n, Kc).permute(1, 2, 0)), dim=0,
+                     dtype=torch.float32)
 
 
 def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
@@ -98,12 +100,43 @@ def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
     if n == 1:
         return torch.mm(a_cm, b_tm).float()
     Kc = T // n
-    return torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_tm.view(n, Kc, -1)).float().sum(0)
+    return torch.sum(torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_tm.view(n, Kc, -1)), dim=0, dtype=torch.float32)
 
 
 # The two scans of a BiMamba layer share the gate z and the upstream gradient: set 0's backward kernel evaluates the gate
 # gradient of both (cad_scan_bwd_args.out2).  CADUCEUS_AMD_SHARED_GATE=0 keeps one dz per set + an add (A/B switch).
 _SHARED_GATE = os.environ.get("CADUCEUS_AMD_SHARED_GATE", "1") != "0"
+
+
+def prepare_step_cache(pairs, act: torch.dtype) -> None:
+    """Compute-dtype copies of every layer's projection weights and A = -exp(A_log), for ALL layers at once with
+    multi-tensor (foreach) launches -- instead of ten tiny cast / exp / neg kernels per layer per step
+    (profiles/r02_step_trace.txt: ~1000 sub-5-us launches per step).  pairs: [(mamba_fwd, mamba_rev)] of the layers that run
+    BiMambaMixerFn.  The copies are attached to mamba_fwd together with the parameter versions they were made from;
+    BiMambaMixerFn.forward uses them only while those versions are current."""
+    if not pairs:
+        return
+    src, dst, alog, owners = [], [], [], []
+    for mf, mr in pairs:
+        ps = [mf.in_proj.weight, mf.out_proj.weight, mf.x_proj.weight, mf.dt_proj.weight, mr.x_proj.weight,
+              mr.dt_proj.weight]
+        out = [torch.empty(p.shape, dtype=act, device=p.device) for p in ps]
+        src += [p.detach() for p in ps]
+        dst += out
+        alog += [mf.A_log.detach().float(), mr.A_log.detach().float()]
+        owners.append((mf, ps + [mf.A_log, mr.A_log], out))
+    torch._foreach_copy_(dst, src)
+    negA = torch._foreach_exp(alog)
+    torch._foreach_neg_(negA)
+    for i, (mf, ps, out) in enumerate(owners):
+        mf._cad_step_cache = {"versions": [(id(p), p._version) for p in ps], "w": out, "A": (negA[2 * i], negA[2 * i + 1])}
+
+
+def _cached(mf, params):
+    c = getattr(mf, "_cad_step_cache", None)
+    if c is None or c["versions"] != [(id(p), p._version) for p in params]:
+        return None
+    return c
 
 
 class BiMambaMixerFn(torch.autograd.Function):
@@ -113,13 +146,15 @@ class BiMambaMixerFn(torch.autograd.Function):
     conv_w (E,1,K), conv_b (E), W_x (R+2N, E), W_dt (E, R), dt_bias (E), A_log (E, N), D (E)."""
 
     @staticmethod
-    def forward(ctx, x2d, SB, Lq, split, W_in, W_out, *ps):
+    def forward(ctx, x2d, SB, Lq, split, cache, W_in, W_out, *ps):
         lib = L.get_lib()
         act = x2d.dtype
         T, Dm = x2d.shape
         E = W_in.shape[0] // 2
-        w_in = W_in.to(act)
-        w_out = W_out.to(act)
+        if cache is not None and cache["w"][0].dtype != act:
+            cache = None
+        w_in = cache["w"][0] if cache else W_in.to(act)
+        w_out = cache["w"][1] if cache else W_out.to(act)
         if ops.proj_supported(x2d, Dm):  # bf16: our W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
             xz = ops.proj_wxT(w_in, x2d).view(2 * E, SB, Lq)
         else:
@@ -138,10 +173,10 @@ class BiMambaMixerFn(torch.autograd.Function):
             N, R = A_log.shape[1], W_dt.shape[1]
             wf, bf = cparams[i]
             xc = xcs[i]
-            w_x, w_dt = W_x.to(act), W_dt.to(act)
+            w_x, w_dt = (cache["w"][2 + 2 * i], cache["w"][3 + 2 * i]) if cache else (W_x.to(act), W_dt.to(act))
             dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
             delta = torch.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
-            A = -torch.exp(A_log.float())
+            A = cache["A"][i] if cache else -torch.exp(A_log.float())
             sets.append((xc, delta, A, dbc, Dp.float().contiguous(), dt_bias.float().contiguous(), wf, bf, w_x, w_dt))
         # both parameter sets in one scan launch
         args = (L.ScanArgs * 2)()
@@ -255,7 +290,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             dxz[E:].add_(dz_r)
         dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
         dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
-        return (dx2d, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
+        return (dx2d, None, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
 
 
 def can_use(mamba_fwd, mamba_rev, strategy) -> bool:
@@ -273,6 +308,9 @@ def bimamba_mixer(hn: torch.Tensor, mamba_fwd, mamba_rev, split: int) -> torch.T
     ps = []
     for m in (mamba_fwd, mamba_rev):
         ps += [m.conv1d.weight, m.conv1d.bias, m.x_proj.weight, m.dt_proj.weight, m.dt_proj.bias, m.A_log, m.D]
-    out = BiMambaMixerFn.apply(hn.reshape(S * B * Lq, Dm), S * B, Lq, split, mamba_fwd.in_proj.weight,
+    cache = _cached(mamba_fwd, [mamba_fwd.in_proj.weight, mamba_fwd.out_proj.weight, mamba_fwd.x_proj.weight,
+                                mamba_fwd.dt_proj.weight, mamba_rev.x_proj.weight, mamba_rev.dt_proj.weight,
+                                mamba_fwd.A_log, mamba_rev.A_log])
+    out = BiMambaMixerFn.apply(hn.reshape(S * B * Lq, Dm), S * B, Lq, split, cache, mamba_fwd.in_proj.weight,
                                mamba_fwd.out_proj.weight, *ps)
     return out.view(S, B, Lq, Dm)

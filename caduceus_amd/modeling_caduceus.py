@@ -16,9 +16,10 @@ from transformers import PreTrainedModel
 from transformers.modeling_outputs import BaseModelOutputWithNoAttention, MaskedLMOutput, SequenceClassifierOutput
 
 from . import engine, ops
+from . import mixer as mixer_sched
 from .configuration_caduceus import CaduceusConfig
 from .mamba import Block, Mamba, RMSNorm, act_dtype_of, norm_params
-from .modeling_rcps import RCPSAddNormWrapper, RCPSEmbedding, RCPSLMHead, RCPSMambaBlock
+from .modeling_rcps import RCPSAddNormWrapper, RCPSEmbedding, RCPSLMHead, RCPSMambaBlock, RCPSWrapper
 
 
 def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, rms_norm=False, residual_in_fp32=False,
@@ -142,6 +143,14 @@ class CaduceusMixerModel(nn.Module):
             act = act_dtype_of(w)
             hidden = self.embeddings.forward_tframe(input_ids, torch.float32 if w.dtype == torch.float32 else act)
         residual = None
+        if act != torch.float32:  # one multi-tensor cast of every layer's projection weights (mixer.prepare_step_cache)
+            pairs = []
+            for layer in self.layers:
+                m = layer.mixer.submodule if isinstance(layer.mixer, RCPSWrapper) else layer.mixer
+                if isinstance(m, BiMambaWrapper) and m.bidirectional and \
+                        mixer_sched.can_use(m.mamba_fwd, m.mamba_rev, m.bidirectional_strategy):
+                    pairs.append((m.mamba_fwd, m.mamba_rev))
+            mixer_sched.prepare_step_cache(pairs, act)
         for layer in self.layers:
             if collect is not None:
                 collect.append(hidden)
