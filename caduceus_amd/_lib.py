@@ -89,7 +89,7 @@ class MlmArgs(C.Structure):
 
 class ProjArgs(C.Structure):
     _fields_ = [("W", _p), ("X", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
-                ("ldo", _i64)]
+                ("ldo", _i64), ("acc", _p), ("ldacc", _i64)]
 
 
 class LmHeadArgs(C.Structure):
@@ -128,6 +128,8 @@ SYMBOLS = {
     "cad_scan_tm_scratch_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_proj_wxT": (_i, [C.POINTER(ProjArgs), _p]),
     "cad_proj_supported": (_i, [_i]),
+    "cad_proj_wx": (_i, [C.POINTER(ProjArgs), _p]),
+    "cad_proj_wx_supported": (_i, [_i, _i64]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_lm_head_partials": (_i64, [_i64]),
     "cad_tokenize_mlm": (_i, [C.POINTER(MlmArgs), _p]),

@@ -264,6 +264,36 @@ __device__ __forceinline__ f32x4 cad_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 
     return __builtin_bit_cast(f32x4, r);
 }
 #endif
+// ds_read_b64_tr_b16: transposing LDS read for 16-bit elements.  Within every 16-lane group, lane 4 r + c (r, c in 0..3)
+// supplies the address of 4 contiguous elements S[r][4c .. 4c+3] of a 4 x 16 block S; lane l of the group receives the
+// COLUMN  (S[0][l], S[1][l], S[2][l], S[3][l]).  This is how a [k][token] tile (token-contiguous, as the channel-major
+// activations are) yields MFMA operand fragments, which want consecutive k per lane.  (Semantics as used by ck_tile's
+// transpose loads, /opt/rocm/include/ck_tile/core/tensor/load_tile_transpose.hpp: Quad16 input / output encodings.)
+#ifdef CAD_EMU
+__device__ __forceinline__ u32x2 cad_lds_read_tr16(const void* p) {
+    uint64_t mine;
+    std::memcpy(&mine, p, 8);
+    const int lane = emu::lane_id();
+    const int base = lane & ~15, l = lane & 15;
+    uint32_t e[4];
+    for (int r = 0; r < 4; ++r) {
+        const uint64_t v = emu_exchange(mine, base + 4 * r + (l >> 2));
+        e[r] = (uint32_t)((v >> (16 * (l & 3))) & 0xffffu);
+    }
+    u32x2 out;
+    out[0] = e[0] | (e[1] << 16);
+    out[1] = e[2] | (e[3] << 16);
+    return out;
+}
+#else
+__device__ __forceinline__ u32x2 cad_lds_read_tr16(const void* p) {
+    typedef __bf16 bf16x4_hw __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) bf16x4_hw lds_vec_t;
+    const bf16x4_hw v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_vec_t*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+#endif
+
 // two fp32 -> packed bf16x2 through a conversion the COMPILER sees (it emits v_cvt_pk_bf16_f32 and pads the MFMA / DOT
 // result hazards itself; the inline-asm cad_pack_bf16x2 is invisible to its hazard recognizer)
 __device__ __forceinline__ uint32_t cad_pack_bf16x2_safe(float lo, float hi) {

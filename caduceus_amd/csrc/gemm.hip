@@ -164,6 +164,150 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
     }
 }
 
+// ---- cad_proj_wx:  out (M, T) = W (M, K) . X (K, T) [+ acc (M, T)],  all channel-major, small K (<= 64) -------------------
+// dt_proj (K = dt_rank) and the x_proj input gradient d(xc) = du + W_x^T . d(dbc) (K = dt_rank + 2 d_state): the
+// streaming operands are the (M, T) output (and addend); X is a thin (K, T) panel.  Same skeleton as proj_wxT_kernel --
+// W-stationary B-fragments, 64-token blocks by LDS-DMA, the D lanes' four consecutive tokens through the per-wave staging
+// tile -- except that X is token-contiguous, so the A-fragments (consecutive k per lane) are TRANSPOSED on the way out
+// of LDS: ds_read_b64_tr_b16 on the [k][token] tile (cad_lds_read_tr16), two reads per 8 k.  Rows k >= K of the tile are
+// zero (written once), so K is padded to 32 / 64 for free.  The 32-byte token segments of a tile row are XOR-swizzled
+// with the row (through the DMA source address) so that the eight rows a transposing read touches hit distinct banks.
+template <int KS>
+struct GxCfg {
+    static constexpr int MB = 4, MW = 64, MWG = MW * GP_WAVES, NT = 64;
+    static constexpr int KP = 32 * KS;               // tile rows (K padded)
+    static constexpr int XROW = NT * 2;              // bytes per tile row
+    static constexpr int XBUF = KP * XROW;
+    static constexpr int SSTR = NT * 2 + 16;
+    static constexpr int STAGE = MW * SSTR;
+    static constexpr size_t LDS = 2 * (size_t)XBUF + (size_t)GP_WAVES * STAGE;
+};
+__device__ __forceinline__ int gx_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+template <int KS>
+__device__ __forceinline__ void gx_issue_block(const bf16_t* X, int64_t ldx, int K, int64_t t0, int64_t T, char* xbuf,
+                                               int wave, int lane) {
+    const int ninstr = K / 8;  // K rows x 8 pieces of 16 bytes, 64 pieces per DMA instruction
+    for (int ins = wave; ins < ninstr; ins += GP_WAVES) {  // wave-uniform
+        const int p = ins * 64 + lane;
+        const int row = p >> 3, pp = p & 7;                        // tile row, PHYSICAL piece
+        const int lp = (((pp >> 1) ^ gx_swz(row)) << 1) | (pp & 1);  // logical piece = 8 tokens
+        int64_t tok = t0 + lp * 8;
+        tok = tok + 8 <= T ? tok : T - 8;                          // tail block: valid data, never stored
+        cad_glds16(X + (int64_t)row * ldx + tok, cad_uniform((int)(cad_lds_off(xbuf) + ins * 1024)));
+    }
+}
+
+template <int KS, bool ACC>
+__global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wx_kernel(cad_proj_args a) {
+    typedef GxCfg<KS> C;
+    CAD_DYN_SMEM(char, smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const int g = lane >> 4, jl = lane & 15;
+    const bf16_t* W = (const bf16_t*)a.W;
+    const bf16_t* X = (const bf16_t*)a.X;
+    const bf16_t* acc = (const bf16_t*)a.acc;
+    bf16_t* out = (bf16_t*)a.out;
+    const int64_t T = a.T;
+    const int M = a.M, K = a.K;
+    const int m_wave = blockIdx.y * C::MWG + wave * C::MW;
+    const int64_t nblk = (T + C::NT - 1) / C::NT;
+    const int64_t b0 = blockIdx.x, bstep = gridDim.x;
+    if (b0 >= nblk) return;
+    char* xb[2] = {smem, smem + C::XBUF};
+    char* stage = smem + 2 * C::XBUF + wave * C::STAGE;
+    // rows K .. KP-1 of both tiles stay zero for the whole launch
+    for (int i = threadIdx.x * 16; i < 2 * C::XBUF; i += 64 * GP_WAVES * 16) {
+        const int row = (i % C::XBUF) / C::XROW;
+        if (row >= K) *(u32x4*)(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    }
+    gx_issue_block<KS>(X, a.ldx, K, b0 * C::NT, T, xb[0], wave, lane);
+    u32x4 wf[C::MB][KS];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+        const int m = m_wave + mb * 16 + jl;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int k0 = ks * 32 + g * 8;
+            if (m < M && k0 + 8 <= K) v = *(const u32x4*)(W + (int64_t)m * a.ldw + k0);
+            wf[mb][ks] = v;
+        }
+    }
+    gp_wait_dma();
+    __syncthreads();
+
+    int cur = 0;
+    for (int64_t b = b0; b < nblk; b += bstep, cur ^= 1) {
+        if (b + bstep < nblk) gx_issue_block<KS>(X, a.ldx, K, (b + bstep) * C::NT, T, xb[cur ^ 1], wave, lane);
+        const char* xt = xb[cur];
+        const int64_t t0 = b * C::NT;
+        constexpr int LPR = C::NT / 8, RPI = 64 / LPR;
+        // the addend rows of this block (plain loads, issued ahead of the MFMA phase)
+        u32x4 old[C::MW / RPI];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int r0 = 0; r0 < C::MW; r0 += RPI) {
+                const int m = m_wave + r0 + lane / LPR;
+                const int64_t t = t0 + (lane % LPR) * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (m < M && t + 8 <= T) v = *(const u32x4*)(acc + (int64_t)m * a.ldacc + t);
+                old[r0 / RPI] = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C::NT / 16; ++q) {
+            // A fragments by transposing reads: lane (token 16 q + jl, group g) gets k = 32 ks + 8 g .. + 7
+            u32x4 xf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int r0 = ks * 32 + g * 8 + (jl >> 2);  // this lane's SOURCE row of the first 4 x 16 block
+                const char* p0 = xt + r0 * C::XROW + ((q ^ gx_swz(r0)) * 32) + (jl & 3) * 8;
+                const char* p1 = xt + (r0 + 4) * C::XROW + ((q ^ gx_swz(r0 + 4)) * 32) + (jl & 3) * 8;
+                const u32x2 lo = cad_lds_read_tr16(p0), hi = cad_lds_read_tr16(p1);
+                xf[ks] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            f32x4 d[C::MB];
+#pragma unroll
+            for (int mb = 0; mb < C::MB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int mb = 0; mb < C::MB; ++mb) d[mb] = cad_mfma_16x16x32_bf16(xf[ks], wf[mb][ks], d[mb]);
+            }
+#pragma unroll
+            for (int mb = 0; mb < C::MB; ++mb) {
+                u32x2 pk;
+                pk[0] = cad_pack_bf16x2_safe(d[mb][0], d[mb][1]);
+                pk[1] = cad_pack_bf16x2_safe(d[mb][2], d[mb][3]);
+                *(u32x2*)(stage + (mb * 16 + jl) * C::SSTR + (q * 16 + g * 4) * 2) = pk;
+            }
+        }
+        asm volatile("" ::: "memory");
+        cad_wave_sync();
+        gp_wait_dma();
+#pragma unroll
+        for (int r0 = 0; r0 < C::MW; r0 += RPI) {
+            const int r = r0 + lane / LPR, c8 = lane % LPR;
+            u32x4 v = *(const u32x4*)(stage + r * C::SSTR + c8 * 16);
+            const int m = m_wave + r;
+            const int64_t t = t0 + c8 * 8;
+            if constexpr (ACC) {  // out = bf16(acc + bf16 product): element-wise on the packed pairs
+                const u32x4 o = old[r0 / RPI];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = cad_bits2f(v[e] << 16) + cad_bits2f(o[e] << 16);
+                    const float hi = cad_bits2f(v[e] & 0xFFFF0000u) + cad_bits2f(o[e] & 0xFFFF0000u);
+                    v[e] = cad_pack_bf16x2(lo, hi);
+                }
+            }
+            if (m < M && t + 8 <= T) *(u32x4*)(out + (int64_t)m * a.ldo + t) = v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // more than 64 KB of dynamic LDS has to be requested per kernel (once)
@@ -211,4 +355,36 @@ extern "C" int cad_proj_wxT(const cad_proj_args* a, void* stream) {
         case 512: return launch_wxT<16>(a, stream);
         default: return CAD_ERR_UNSUPPORTED;
     }
+}
+
+
+template <int KS>
+static int launch_wx(const cad_proj_args* a, void* stream) {
+    typedef GxCfg<KS> C;
+    const int64_t nblk = (a->T + C::NT - 1) / C::NT;
+    const int my = (a->M + C::MWG - 1) / C::MWG;
+    int64_t gx = 256 / my;
+    if (gx < 1) gx = 1;
+    if (gx > nblk) gx = nblk;
+    dim3 grid((unsigned)gx, (unsigned)my), block(64 * GP_WAVES);
+    if (a->acc) {
+        GP_BIG_LDS((proj_wx_kernel<KS, true>), C::LDS);
+        CAD_LAUNCH((proj_wx_kernel<KS, true>), grid, block, C::LDS, stream, *a);
+    } else {
+        GP_BIG_LDS((proj_wx_kernel<KS, false>), C::LDS);
+        CAD_LAUNCH((proj_wx_kernel<KS, false>), grid, block, C::LDS, stream, *a);
+    }
+    return cad_after_launch();
+}
+
+extern "C" int cad_proj_wx_supported(int K, int64_t T) { return K >= 8 && K <= 64 && (K % 8) == 0 && T >= 8 && (T % 8) == 0; }
+
+extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->W && a->X && a->out && a->T > 0 && a->M > 0 && a->K > 0);
+    if (!cad_proj_wx_supported(a->K, a->T)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T && (a->acc == nullptr || a->ldacc >= a->T));
+    CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 8) == 0 && (a->ldacc % 8) == 0);
+    CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X | (uintptr_t)a->out | (uintptr_t)a->acc) % 16) == 0);
+    CadProfScope prof(8, stream);
+    return a->K <= 32 ? launch_wx<1>(a, stream) : launch_wx<2>(a, stream);
 }

@@ -54,6 +54,9 @@ struct ScanBwdSets {
                                         // the ds_read_b128 of the four channel groups are conflict-free)
 #define PK_BUF (SC_W * 2 * PK_TILE)     // dwords per buffer
 // LDS-DMA prefetch of the next chunk's item vectors (bf16 production kernel): 6 vectors x SC_W waves x 64 lanes x 16 bytes
+#ifndef SC_BWD_SLAB_SWZ
+#define SC_BWD_SLAB_SWZ 1  // exchange the item pairs of a slab piece on lanes 8..15 of every 16 (bank swizzle)
+#endif
 #ifndef SC_BWD_PREFETCH
 #define SC_BWD_PREFETCH 1
 #endif
@@ -384,7 +387,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     if (i & 1) {
                         pkB = pB, pkC = pC;  // the odd item waits for its even partner: one 8-byte store per item pair
                     } else {
-                        uint32_t* qB = accp + buf * PK_BUF + wave * 2 * PK_TILE + (i >> 2) * PK_Q + lane * 4 + ((i >> 1) & 1) * 2;
+                        // (the two item pairs of a piece trade places on lanes 8..15 of every 16: the 8-byte stores of a
+                        // 16-lane group then cover all 32 banks once -- measured 31 % conflict cycles without it)
+                        uint32_t* qB = accp + buf * PK_BUF + wave * 2 * PK_TILE + (i >> 2) * PK_Q + lane * 4 +
+                                       ((((i >> 1) ^ ((lane >> 3) & SC_BWD_SLAB_SWZ)) & 1) * 2);
                         *(u32x2*)qB = u32x2{pB, pkB};
                         *(u32x2*)(qB + PK_TILE) = u32x2{pC, pkC};
                     }
@@ -432,7 +438,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     d0 = cad_mfma_16x16x32_bf16(selA, b0, d0);
                     d1 = cad_mfma_16x16x32_bf16(selA, b1, d1);
                 }
-                // lanes 0..31: g = state of the pair; d0 = items 0..3, d1 = items 4..7 of lane (jb, jl)
+                // lanes 0..31: g = state of the pair; d0 = items 0..3, d1 = items 4..7 of lane (jb, jl); pieces of lanes with
+                // bit 3 set were stored with their item pairs exchanged (bank swizzle of the slab writes)
+                if (SC_BWD_SLAB_SWZ && (jl & 8)) {
+                    d0 = f32x4{d0[2], d0[3], d0[0], d0[1]};
+                    d1 = f32x4{d1[2], d1[3], d1[0], d1[1]};
+                }
                 if (g < 2 && n0 + g < N) {
                     const int64_t p = base + (int64_t)(jb * 16 + jl) * SC_S;
                     // row (state n0 + g) of this workgroup's slot: scalar base + one per-lane select (g is 0 or 1 here)

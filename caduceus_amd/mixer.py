@@ -175,7 +175,10 @@ class BiMambaMixerFn(torch.autograd.Function):
             xc = xcs[i]
             w_x, w_dt = (cache["w"][2 + 2 * i], cache["w"][3 + 2 * i]) if cache else (W_x.to(act), W_dt.to(act))
             dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
-            delta = torch.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
+            if ops.proj_wx_supported(xc, R, T):  # thin-K MFMA kernel (transposing LDS reads), csrc/gemm.hip
+                delta = ops.proj_wx(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
+            else:
+                delta = torch.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
             A = cache["A"][i] if cache else -torch.exp(A_log.float())
             sets.append((xc, delta, A, dbc, Dp.float().contiguous(), dt_bias.float().contiguous(), wf, bf, w_x, w_dt))
         # both parameter sets in one scan launch
@@ -275,7 +278,11 @@ class BiMambaMixerFn(torch.autograd.Function):
             torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
             dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
-            du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))  # in place: no copy of the 268 MB addend
+            # d(xc) = du + W_x^T . d(dbc), in place (no copy of the 268 MB addend)
+            if ops.proj_wx_supported(du, R + 2 * N, T):
+                ops.proj_wx(w_x.t().contiguous(), ddbc.view(R + 2 * N, T), out=du.view(E, T), acc=du.view(E, T))
+            else:
+                du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))
             dxcs.append(du)
             part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
         conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs,

@@ -463,6 +463,27 @@ def proj_wxT(W: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = Non
     if out is None:
         out = torch.empty((M, T), dtype=torch.bfloat16, device=X.device)
     stream = L.stream_and_check(W, X, out, contiguous=False)
-    a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0))
+    a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0), None, 0)
     L.check(L.get_lib().cad_proj_wxT(C.byref(a), stream), "cad_proj_wxT")
+    return out
+
+
+def proj_wx_supported(t: torch.Tensor, K: int, T: int) -> bool:
+    return t.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_wx_supported(int(K), int(T)))
+
+
+def proj_wx(W: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None,
+            acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (M, T) = W (M, K) @ X (K, T) [+ acc (M, T)], all channel-major bf16, thin K (cad_proj_wx).  `acc` may be `out`
+    itself (in-place accumulate)."""
+    M, K = W.shape
+    T = X.shape[1]
+    if X.shape[0] != K or W.stride(1) != 1 or X.stride(1) != 1:
+        raise ValueError("proj_wx: W (M, K) and X (K, T) with unit inner stride")
+    if out is None:
+        out = torch.empty((M, T), dtype=torch.bfloat16, device=X.device)
+    stream = L.stream_and_check(W, X, out, acc, contiguous=False)
+    a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0), L.ptr(acc),
+                   0 if acc is None else acc.stride(0))
+    L.check(L.get_lib().cad_proj_wx(C.byref(a), stream), "cad_proj_wx")
     return out

@@ -315,9 +315,17 @@ typedef struct {
     int64_t T;
     int M, K;
     int64_t ldw, ldx, ldo;
+    const void* acc;   /* cad_proj_wx only: optional (M, T) addend, may alias out; NULL = none */
+    int64_t ldacc;
 } cad_proj_args;
 int cad_proj_wxT(const cad_proj_args* a, void* stream);
 int cad_proj_supported(int K);
+/* cad_proj_wx:  out (M, T) = W (M, K) . X (K, T) [+ acc],  all channel-major, thin K (cad_proj_wx_supported: K <= 64,
+ * K % 8 == 0, T % 8 == 0) -- dt_proj (K = dt_rank; `dt_proj` inside mamba_inner_fn) and the x_proj input gradient
+ * d(xc) = du + W_x^T . d(dbc) of its backward.  X is token-contiguous: the MFMA fragments are transposed on the way out
+ * of LDS (ds_read_b64_tr_b16). */
+int cad_proj_wx(const cad_proj_args* a, void* stream);
+int cad_proj_wx_supported(int K, int64_t T);
 
 /* ---------------------------------------------------------------------------------------------------------
  * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()

@@ -46,3 +46,21 @@ def test_proj_wxT_strided_views(backend):
     ref = (Wb[:, :K].float() @ Xb[:, :K].float().t()).to(torch.bfloat16)
     torch.testing.assert_close(outb[:, :T].float().cpu(), ref.float(), rtol=2e-2, atol=2e-2)
     assert float(outb[:, T:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,T", [(512, 16, 256), (96, 48, 200), (64, 8, 72), (130, 40, 64), (512, 48, 192)])
+@pytest.mark.parametrize("acc", [False, True])
+def test_proj_wx(backend, M, K, T, acc):
+    """Thin-K channel-major product (dt_proj; the x_proj input gradient with its addend), transposing LDS reads."""
+    name, dev = backend
+    W, X = _bf(M, K, seed=11), _bf(K, T, seed=12)
+    A = _bf(M, T, seed=13) if acc else None
+    out = ops.proj_wx(W.to(dev), X.to(dev), acc=None if A is None else A.to(dev))
+    ref = W.float() @ X.float()
+    if acc:
+        ref = ref.to(torch.bfloat16).float() + A.float()
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
+    if acc:  # in place
+        buf = A.clone().to(dev)
+        ops.proj_wx(W.to(dev), X.to(dev), out=buf, acc=buf)
+        assert torch.equal(buf.cpu(), out.cpu())

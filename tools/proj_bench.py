@@ -43,3 +43,29 @@ for name, W, X in (("in_proj W(1024x256) . x^T", w_in, x2d), ("dy W_out^T(512x25
                  "max_abs_diff_vs_hipblaslt": err}
     print(name, res[name])
 print(json.dumps(res))
+
+# thin-K channel-major products (transposing LDS reads): dt_proj and the x_proj input gradient with its addend
+R, N = 16, 16
+w_dt, dt_lr = r(E, R) * 0.2, r(R, T)
+w_xT, ddbc, du = (r(R + 2 * N, E) * 0.06).t().contiguous(), r(R + 2 * N, T), r(E, T)
+for name, W, X, acc in (("dt_proj W(512x16) . dt_lr(16xT)", w_dt, dt_lr, None),
+                        ("du += W_x^T(512x48) . ddbc(48xT)", w_xT, ddbc, du)):
+    M, K = W.shape
+    if not ops.proj_wx_supported(K, T):
+        continue
+    ours = ops.proj_wx(W, X, acc=acc)
+    ref = torch.mm(W, X) if acc is None else (torch.mm(W, X) + acc)
+    err = float((ours.float() - ref.float()).abs().max())
+    if acc is None:
+        t_ours = timeit(lambda: ops.proj_wx(W, X))
+        t_lib = timeit(lambda: torch.mm(W, X))
+    else:
+        buf = acc.clone()
+        t_ours = timeit(lambda: ops.proj_wx(W, X, out=buf, acc=buf))
+        buf2 = acc.clone()
+        t_lib = timeit(lambda: buf2.addmm_(W, X))
+    by = (T * K + M * K + M * T * (2 if acc is not None else 1)) * 2
+    res[name] = {"ours_ms": round(t_ours, 4), "hipblaslt_ms": round(t_lib, 4), "ours_GBps": round(by / t_ours / 1e6, 1),
+                 "hipblaslt_GBps": round(by / t_lib / 1e6, 1), "max_abs_diff_vs_hipblaslt": err}
+    print(name, res[name])
+print(json.dumps(res))
