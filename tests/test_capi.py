@@ -18,7 +18,7 @@ def _header_text():
 
 
 def _header_functions():
-    return set(re.findall(r"\b(cad_[a-z0-9_]+)\s*\(", _header_text()))
+    return set(re.findall(r"\b(cad_[A-Za-z0-9_]+)\s*\(", _header_text()))
 
 
 def _header_structs():
