@@ -228,7 +228,7 @@ def main():
         # rocprofv3 --pmc at exactly this launch shape); null for any other shape
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_scan_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_scan_pmc.json")))
             sh = pmc["shape"]
             if dom and (sh["E"], sh["L"], sh["N"], sh["dtype"]) == (E, args.seqlen, N, args.dtype) and \
                     sh["rows"] == (2 if args.model == "ps" else 1) * args.batch:
@@ -238,7 +238,7 @@ def main():
         if dom:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": kinds[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": kinds[dom]["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_note": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_scan_pmc.json)",
+                        "traffic_note": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_scan_pmc.json)",
                         "avg_launch_ms": kinds[dom]["avg_ms"], "launches": kinds[dom]["launches"],
                         "algorithmic_bytes_per_launch": kinds[dom]["algorithmic_bytes_per_launch"],
                         "all": {k: {"avg_ms": v["avg_ms"], "achieved_GBps": v["achieved_GBps"],

@@ -55,7 +55,8 @@ struct ScanBwdSets {
 #define PK_BUF (SC_W * 2 * PK_TILE)     // dwords per buffer
 // LDS-DMA prefetch of the next chunk's item vectors (bf16 production kernel): 6 vectors x SC_W waves x 64 lanes x 16 bytes
 #ifndef SC_BWD_SLAB_SWZ
-#define SC_BWD_SLAB_SWZ 1  // exchange the item pairs of a slab piece on lanes 8..15 of every 16 (bank swizzle)
+#define SC_BWD_SLAB_SWZ 0  // 1: exchange the item pairs of a slab piece on lanes 8..15 of every 16 (no bank conflicts on the slab
+                           // writes; measured 1.5 % SLOWER: the 8 selects after the MFMA cost more than the conflicts, which hide)
 #endif
 #ifndef SC_BWD_PREFETCH
 #define SC_BWD_PREFETCH 1
@@ -191,15 +192,20 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const char* slot = pre + wave * (64 * 16) + lane * 16;
             const bool in = p0 < L;
             typedef ScVec<T, SC_S> V;
-            V zero;
-#pragma unroll
-            for (int j = 0; j < SC_S; ++j) zero.v[j] = from_f32<T>(0.f);
-            u_raw = in ? *(const V*)slot : zero;
-            d_raw = in ? *(const V*)(slot + PRE_SLOT) : zero;
-            g_raw = in ? *(const V*)(slot + 2 * PRE_SLOT) : zero;
-            if (z_row) z_raw = in ? *(const V*)(slot + 3 * PRE_SLOT) : zero;
-            if (o_row) o_raw = in ? *(const V*)(slot + 4 * PRE_SLOT) : zero;
-            if (o2_row) o2_raw = in ? *(const V*)(slot + 5 * PRE_SLOT) : zero;
+            // (unconditional LDS read, then a mask: `in ? *slot : zero` is compiled to a select between the slot's address
+            // and a zero vector kept in scratch, read back through flat loads -- 0.4 GB of scratch stores per launch)
+            const uint32_t keepm = in ? 0xffffffffu : 0u;
+            auto rd = [&](int k) {
+                u32x4 v = *(const u32x4*)(slot + k * PRE_SLOT);
+                v[0] &= keepm, v[1] &= keepm, v[2] &= keepm, v[3] &= keepm;
+                return __builtin_bit_cast(V, v);
+            };
+            u_raw = rd(0);
+            d_raw = rd(1);
+            g_raw = rd(2);
+            if (z_row) z_raw = rd(3);
+            if (o_row) o_raw = rd(4);
+            if (o2_row) o2_raw = rd(5);
         }
         {
             float uu[SC_S], dt[SC_S], dy[SC_S];
@@ -387,8 +393,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     if (i & 1) {
                         pkB = pB, pkC = pC;  // the odd item waits for its even partner: one 8-byte store per item pair
                     } else {
-                        // (the two item pairs of a piece trade places on lanes 8..15 of every 16: the 8-byte stores of a
-                        // 16-lane group then cover all 32 banks once -- measured 31 % conflict cycles without it)
+                        // (8-byte stores at a 16-byte lane stride: 2-way bank conflicts, 31 % of the LDS cycles -- see
+                        // SC_BWD_SLAB_SWZ for the swizzle that removes them and why it is off)
                         uint32_t* qB = accp + buf * PK_BUF + wave * 2 * PK_TILE + (i >> 2) * PK_Q + lane * 4 +
                                        ((((i >> 1) ^ ((lane >> 3) & SC_BWD_SLAB_SWZ)) & 1) * 2);
                         *(u32x2*)qB = u32x2{pB, pkB};

@@ -51,7 +51,7 @@ w_xT, ddbc, du = (r(R + 2 * N, E) * 0.06).t().contiguous(), r(R + 2 * N, T), r(E
 for name, W, X, acc in (("dt_proj W(512x16) . dt_lr(16xT)", w_dt, dt_lr, None),
                         ("du += W_x^T(512x48) . ddbc(48xT)", w_xT, ddbc, du)):
     M, K = W.shape
-    if not ops.proj_wx_supported(K, T):
+    if not ops.proj_wx_supported(W, K, T):
         continue
     ours = ops.proj_wx(W, X, acc=acc)
     ref = torch.mm(W, X) if acc is None else (torch.mm(W, X) + acc)
