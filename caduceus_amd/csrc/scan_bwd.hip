@@ -58,6 +58,9 @@ struct ScanBwdSets {
 #define SC_BWD_SLAB_SWZ 0  // 1: exchange the item pairs of a slab piece on lanes 8..15 of every 16 (no bank conflicts on the slab
                            // writes; measured 1.5 % SLOWER: the 8 selects after the MFMA cost more than the conflicts, which hide)
 #endif
+#ifndef SC_BWD_PK_ACC
+#define SC_BWD_PK_ACC 1  // packed per-item accumulators of d(delta) / <g, B> (16 VGPRs for 16 VALU instructions per pair-step)
+#endif
 #ifndef SC_BWD_PREFETCH
 #define SC_BWD_PREFETCH 1
 #endif
@@ -168,10 +171,21 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         const float* gp = a.dhT + ((int64_t)e * SB + sb) * N + 2 * lane;
         carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
     }
-    f32x2 hin_next = f2(0.f);
-    if (lane < NP) {
-        const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + nchunks - 1) * NP + lane) * 2;
-        hin_next = f2(stp[0], stp[1]);
+    // state entering this lane's segment, per pair: the forward saved the running state at the end of every SC_S
+    // positions (lane-boundary states, scan_common.h); block 0 of the row starts from the state at the row's start
+    // (first chunk-state slot = h0 or zero).  Loaded asynchronously one pair-step ahead, see sc_async_wait_keep1 below.
+    const int64_t ls_nblk = sc_ls_blocks(L);
+    const float* ls_base = a.chunk_state + sc_ls_offset(a.E, SB, L, N) + ((int64_t)e * SB + sb) * NP * ls_nblk * 2;
+    const float* cs0 = a.chunk_state + ((int64_t)e * SB + sb) * nchunks * NP * 2;
+    auto ls_ptr = [&](int64_t cq, int npq) {
+        const int64_t k = cq * 64 + lane;
+        return k == 0 ? cs0 + npq * 2 : ls_base + ((int64_t)npq * ls_nblk + k - 1) * 2;
+    };
+    f32x2 hs_next;
+    {
+        f32x2 fly;
+        sc_async_load(fly, ls_ptr(nchunks - 1, 0));
+        hs_next = sc_async_wait_take1(fly, false);
     }
     f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
     float dDacc = 0.f, dbacc = 0.f;
@@ -182,7 +196,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
         SC_TIME(0);  // flush tail of the previous pair-step / loop overhead
+#if SC_BWD_PK_ACC
+        f32x2 ddt[SC_S], gBs[SC_S];   // sum over the states (even / odd halves) of g * h_{i-1} * a * A  and of  <g, B>
+#else
         float ddt[SC_S], gBs[SC_S];   // sum over the states of g * h_{i-1} * a * A  and of  <g, B>
+#endif
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
@@ -262,26 +280,24 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const float sp = cad_softplus(dt[i] + bias);
                 const float dti = ok ? sp : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
+#if SC_BWD_PK_ACC
+                ddt[i] = f2(0.f);
+                gBs[i] = f2(0.f);
+#else
                 ddt[i] = 0.f;
                 gBs[i] = 0.f;
+#endif
                 dDacc += dyi * uu[i];
                 dd[i] = f2(dti, dti * uu[i]);
                 sum_dt += dti;
                 dy2[i >> 1][i & 1] = dyi;
             }
         }
-        // running states of all pairs at this chunk's start (saved by the forward): lane np holds pair np; the next
-        // (earlier) chunk's states are fetched now and land while this chunk computes
-        const f32x2 hin_reg = hin_next;
-        if (lane < NP && c > 0) {
-            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c - 1) * NP + lane) * 2;
-            hin_next = f2(stp[0], stp[1]);
-        }
         // per-item outputs of this chunk (all states folded in): u / delta from the raw vectors loaded at the chunk's start.
         // With the LDS-DMA prefetch nothing overwrites those registers, so it runs once BEHIND the pair loop (inside the
         // loop the compiler if-converts it and evaluates its transcendentals in every pair-step).
         auto chunk_epilogue = [&]() {
-            float uu[SC_S], dl[SC_S], du[SC_S];
+            float uu[SC_S], dl[SC_S], du[SC_S], ddo[SC_S];
             sc_unpack<T, SC_S>(u_raw, rev, uu);
             sc_unpack<T, SC_S>(d_raw, rev, dl);
 #pragma unroll
@@ -290,19 +306,29 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
                 const float dyi = dy2[i >> 1][i & 1];
                 const bool ok = VEC ? (p0 < L) : (p0 + i < L);
-                du[i] = dd[i][0] * gBs[i] + dyi * Dv;
-                ddt[i] = ok ? (ddt[i] + uu[i] * gBs[i]) * sg : 0.f;
-                dbacc += ddt[i];
+#if SC_BWD_PK_ACC
+                const float gB = gBs[i][0] + gBs[i][1], dts = ddt[i][0] + ddt[i][1];
+#else
+                const float gB = gBs[i], dts = ddt[i];
+#endif
+                du[i] = dd[i][0] * gB + dyi * Dv;
+                ddo[i] = ok ? (dts + uu[i] * gB) * sg : 0.f;
+                dbacc += ddo[i];
             }
             if (act) {
                 sc_store<T, SC_S, VEC>(du_row, p0, L, rev, du);
-                sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
+                sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddo);
             }
         };
         SC_TIME(1);  // chunk prologue: unpack, gate, softplus
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);
+            const f32x2 h0 = hs_next;  // state entering this lane's segment (landed: waited for in the previous pair-step)
+            // the next pair-step's: issued BEFORE the tile loads / the DMA prefetch, so that the counted wait at the staging
+            // store (vmcnt retires in order) covers it in every wave
+            f32x2 hs_fly;  // (unconditional: the very last pair-step re-reads its own state)
+            sc_async_load(hs_fly, (np + 1 < NP) ? ls_ptr(c, np + 1) : ls_ptr(c > 0 ? c - 1 : 0, 0));
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
@@ -326,32 +352,24 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const int n0 = 2 * np;
             const f32x2 Av = readlane2(Areg, np);
             const f32x2 A2 = Av * f2(CAD_LOG2E);
-            const f32x2 hin = readlane2(hin_reg, np);
             // B and C of this pair are each needed twice (recompute / gradient step, reverse scan / gradient step): read
             // them from the LDS tile once, up front
             f32x2 Cv[SC_S], Bw[SC_S];
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
             SC_TIME(2);  // staging issue + B/C tile reads
-            // 1. forward recompute: serial totals, wave scan, then the true h_i
+            // 1. forward recompute from the saved lane-boundary state h0: no serial pre-pass, no wave scan
             f32x2 av[SC_S], hs[SC_S];
-            f32x2 acc_h = f2(0.f);
             const f32x2 acc_a = exp2_2(f2(sum_dt) * A2);  // product of the lane's a_i
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 av[i] = exp2_2(splat_lo(dd[i]) * A2);
                 hs[i] = splat_hi(dd[i]) * Bw[i];  // b_i
-                acc_h = av[i] * acc_h + hs[i];
             }
-            SC_TIME(3);  // exp + serial scan
-            f32x2 PA = acc_a, PH = acc_h;
-            wave_scan_fwd(PA, PH);
-            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
-            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
-            const f32x2 h0 = ea * hin + eh;  // state entering this lane's segment
+            SC_TIME(3);  // exp
             // the true h_i (forward chain) and 2. the reverse scan of G (backward chain), interleaved: two independent
             // serial v_pk_fma chains, each step of one fills the wait state the other needs between dependent packed ops
-            SC_TIME(4);  // forward wave scan
+            SC_TIME(4);
             f32x2 RG = f2(0.f);
             {
                 f32x2 h = h0;
@@ -364,13 +382,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }
             }
             SC_TIME(5);  // true h + lane-local reverse scan
-            f32x2 QA = acc_a, QG = RG;
-            wave_scan_rev(QA, QG, lane);
-            const f32x2 fa = f2(dpp_wave_shl1(1.f, QA[0]), dpp_wave_shl1(1.f, QA[1]));
-            const f32x2 fg = f2(dpp_wave_shl1(0.f, QG[0]), dpp_wave_shl1(0.f, QG[1]));
+            f32x2 QG = RG;
             const f32x2 gin = readlane2(carryG, np);
-            f32x2 G = fa * gin + fg;  // G_{i+1} for this lane's last item
-            const f32x2 newc = readlane2(QA * gin + QG, 0);
+            wave_scan_rev_carry(acc_a, QG, gin, lane);  // QG: the true G flowing out of each lane
+            f32x2 G = f2(dpp_wave_shl1(gin[0], QG[0]), dpp_wave_shl1(gin[1], QG[1]));  // G_{i+1} for this lane's last item
+            const f32x2 newc = readlane2(QG, 0);
             if (lane == np) carryG = newc;
             SC_TIME(6);  // reverse wave scan + carry
             // 3. gradients
@@ -383,8 +399,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
-                ddt[i] = dot2_acc(ddt[i], t, Av);  // scalar accumulators: the packed form (one v_pk_fma each) needs 16 more
-                gBs[i] = dot2_acc(gBs[i], g, Bv);  // VGPRs, spills, and the spill traffic reaches HBM (+0.75 GB per launch)
+#if SC_BWD_PK_ACC
+                ddt[i] = t * Av + ddt[i];  // one v_pk_fma each (the halves are added once per chunk, in the epilogue)
+                gBs[i] = g * Bv + gBs[i];
+#else
+                ddt[i] = dot2_acc(ddt[i], t, Av);  // scalar accumulators: two v_fmac each, 16 VGPRs less
+                gBs[i] = dot2_acc(gBs[i], g, Bv);
+#endif
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * SC_DY(i);
@@ -413,6 +434,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 if (np == NP - 1) chunk_epilogue();
             }
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
+            hs_next = sc_async_wait_take1(hs_fly, dma_now);  // every wave (only waves 0..3 stage)
             if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
             SC_TIME(9);  // staging store (waits for the tile loads)
             __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible

@@ -35,6 +35,19 @@
 #define SC_OCC 2                // register budget: waves per SIMD the kernels are compiled for
 #endif
 #define SC_STATE_STEP (64 * SC_S_BWD)   // positions between saved running states = the backward's chunk
+// Lane-boundary states: besides the state at every chunk start the forward saves the running state after EVERY
+// SC_S_BWD positions (= at the end of every lane segment of the backward), 8 bytes per (channel row, state pair, 8
+// positions) behind the chunk states in the same buffer.  The backward then starts every lane from its true incoming
+// state: no serial pre-pass, no forward wave scan (45 of ~350 VALU instructions per pair-step of a kernel that is
+// VALU-issue bound, profiles/r02_scan_pmc.json) for 1.07 GB of HBM per scan at E 512 x 2 rows x L 131072 x N 16.
+#define SC_LS_PER_CHUNK ((64 * SC_S_FWD) / SC_S_BWD)   // boundary states per forward chunk and state pair
+static inline __host__ __device__ int64_t sc_ls_blocks(int64_t L) {
+    return (L + 64 * SC_S_FWD - 1) / (64 * SC_S_FWD) * SC_LS_PER_CHUNK;
+}
+static inline __host__ __device__ int64_t sc_ls_offset(int E, int64_t SB, int64_t L, int N) {  // floats before the region
+    const int64_t nslots = (L + 64 * SC_S_BWD - 1) / (64 * SC_S_BWD);
+    return ((int64_t)E * SB * (nslots + 1) * ((N + 1) / 2) * 2 + 3) / 4 * 4;
+}
 #define SC_NMAX 64              // max d_state
 #define SC_MAXSETS 2
 #define SC_ROW(S) (2 * (S) + 4)        // floats per lane row of a B/C tile (S x float2 + 16 B pad -> conflict-free b128)
@@ -267,6 +280,61 @@ __device__ __forceinline__ void wave_scan_rev(f32x2& A, f32x2& G, int lane) {
     }
 }
 
+// The same reverse scan with the carry `gin` (G flowing in behind lane 63, wave-uniform) folded into lane 63's map before
+// the scan: on return G of lane j is the TRUE value flowing out of lane j (towards lane j - 1), the map products A are not
+// needed afterwards (no exclusive shift of A, no `A * gin + G` per lane, no A update in the last step), and the cross-row
+// steps run under an exec mask instead of compute-then-select (2 packed ops + 2 s_mov per step instead of 2 + 4 v_cndmask).
+__device__ __forceinline__ void wave_scan_rev_carry(f32x2 A, f32x2& G, f32x2 gin, int lane) {
+#ifdef CAD_EMU
+    if (lane == 63) G = A * gin + G;
+    wave_scan_rev(A, G, lane);
+#else
+    // every lane of the wave is active here (the pair loop has a wave-uniform trip count): exec is restored to all ones
+    asm volatile(
+        "s_mov_b32 exec_lo, 0\n\t"
+        "s_mov_b32 exec_hi, 0x80000000\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(G)
+        : "v"(A), "s"(gin));
+    {
+        float g0 = G[0], g1 = G[1], a0 = A[0], a1 = A[1];
+        asm("s_nop 1\n\t"
+            SC_KS_ASM("row_shl:1 row_mask:0xf bank_mask:0xf")
+            SC_KS_ASM("row_shl:2 row_mask:0xf bank_mask:0xf")
+            SC_KS_ASM("row_shl:4 row_mask:0xf bank_mask:0xf")
+            SC_KS_ASM("row_shl:8 row_mask:0xf bank_mask:0xf")
+            : "+v"(g0), "+v"(g1), "+v"(a0), "+v"(a1));
+        G = f2(g0, g1);
+        A = f2(a0, a1);
+    }
+    {   // rows 0 and 2 <- total of the next row (lanes 16 / 48)
+        const f32x2 a16 = readlane2(A, 16), g16 = readlane2(G, 16), a48 = readlane2(A, 48), g48 = readlane2(G, 48);
+        asm volatile(
+            "s_mov_b32 exec_lo, 0xffff\n\t"
+            "s_mov_b32 exec_hi, 0\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0\n\t"
+            "v_pk_mul_f32 %1, %1, %3\n\t"
+            "s_mov_b32 exec_lo, 0\n\t"
+            "s_mov_b32 exec_hi, 0xffff\n\t"
+            "v_pk_fma_f32 %0, %1, %4, %0\n\t"
+            "v_pk_mul_f32 %1, %1, %5\n\t"
+            "s_mov_b64 exec, -1"
+            : "+v"(G), "+v"(A)
+            : "s"(g16), "s"(a16), "s"(g48), "s"(a48));
+    }
+    {   // rows 0 and 1 <- total of rows 2..3 (now at lane 32)
+        const f32x2 g32 = readlane2(G, 32);
+        asm volatile(
+            "s_mov_b32 exec_hi, 0\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0\n\t"
+            "s_mov_b64 exec, -1"
+            : "+v"(G)
+            : "v"(A), "s"(g32));
+    }
+#endif
+}
+
 // ---- per-lane item vectors -------------------------------------------------------------------------------------------
 template <typename T, int S>
 struct __attribute__((aligned(16))) ScVec {
@@ -490,6 +558,34 @@ __device__ __forceinline__ void sc_async_wait_keep(V& a, V& b, bool keep_dma) {
         : "s"(k)
         : "memory", "scc");
     a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y);
+#endif
+}
+// the same wait for ONE asynchronously loaded register pair (every wave: the lane-boundary state of the next pair-step),
+// which it returns in FRESH registers: the in-flight pair lives only between the load and this statement of the same
+// iteration (a loop-carried in-flight value would be copied into its phi register by the compiler BEFORE the wait).
+template <typename V>
+__device__ __forceinline__ V sc_async_wait_take1(const V& src, bool keep_dma) {
+#ifndef CAD_EMU
+    static_assert(sizeof(V) == 8, "one float2");
+    typedef uint32_t uw __attribute__((ext_vector_type(2)));
+    const uw x = __builtin_bit_cast(uw, src);
+    uw y;
+    const uint32_t k = __builtin_amdgcn_readfirstlane(keep_dma ? 1u : 0u);
+    asm volatile(
+        "s_cmp_eq_u32 %2, 0\n\t"
+        "s_cbranch_scc1 .Lsc_wait0_%=\n\t"
+        "s_waitcnt vmcnt(6)\n\t"
+        "s_branch .Lsc_waitd_%=\n"
+        ".Lsc_wait0_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n"
+        ".Lsc_waitd_%=:\n\t"
+        "v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]"
+        : "=&v"(y)
+        : "v"(x), "s"(k)
+        : "memory", "scc");
+    return __builtin_bit_cast(V, y);
+#else
+    return src;
 #endif
 }
 static_assert(SC_NDMA == 6, "the immediate of s_waitcnt vmcnt(6) above");

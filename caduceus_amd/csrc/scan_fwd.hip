@@ -138,6 +138,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         const int n0 = 2 * lane;
         Areg = f2(a.A[e * N + n0] * CAD_LOG2E, (n0 + 1 < N) ? a.A[e * N + n0 + 1] * CAD_LOG2E : 0.f);
     }
+    // lane-boundary states for the backward (scan_common.h: SC_LS_PER_CHUNK): [pair][block] float2 per channel row
+    static_assert(SC_S_FWD == SC_S_BWD || SC_S_FWD == 2 * SC_S_BWD, "one or two backward lane segments per forward lane");
+    constexpr int LSR = SC_S_FWD / SC_S_BWD;
+    const int64_t ls_nblk = sc_ls_blocks(L);
+    float* ls_row = (a.chunk_state && act)
+                        ? a.chunk_state + sc_ls_offset(a.E, SB, L, N) + ((int64_t)e * SB + sb) * NP * ls_nblk * 2
+                        : nullptr;
     int tix = 0;            // tiles consumed so far: tile tix lives in LDS buffer tix & 1
     SC_TIME_DECL;
     for (int64_t c = 0; c < nchunks; ++c) {
@@ -232,12 +239,21 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             if (lane == np) carry = newc;
             SC_TIME(3);  // wave scan + carry
             cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
+            f32x2 lsv[LSR];
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
                 const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
                 const f32x4 c4 = *(const f32x4*)(tC + 2 * i);
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
+                if ((i + 2) % SC_S_BWD == 0) lsv[(i + 1) / SC_S_BWD] = hB;  // state at the end of a backward lane segment
+            }
+            if (ls_row) {  // wave-uniform
+                float* q = ls_row + ((int64_t)np * ls_nblk + c * SC_LS_PER_CHUNK + (int64_t)lane * LSR) * 2;
+                if constexpr (LSR == 2)
+                    *(f32x4*)q = f32x4{lsv[0][0], lsv[0][1], lsv[1][0], lsv[1][1]};
+                else
+                    *(f32x2*)q = lsv[0];
             }
             SC_TIME(4);  // output phase (C tile reads)
             if (more) {
@@ -287,7 +303,9 @@ extern "C" int64_t cad_scan_chunk_len(void) { return SC_CHUNK; }
 
 extern "C" int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N) {
     const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
-    return (int64_t)E * SB * (nslots + 1) * ((N + 1) / 2) * 2;
+    (void)nslots;
+    // chunk-start states, then the lane-boundary states (scan_common.h: SC_LS_PER_CHUNK)
+    return sc_ls_offset(E, SB, L, N) + (int64_t)E * SB * ((N + 1) / 2) * sc_ls_blocks(L) * 2;
 }
 
 extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream) {
