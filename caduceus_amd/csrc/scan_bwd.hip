@@ -59,13 +59,21 @@ struct ScanBwdSets {
                            // writes; measured 1.5 % SLOWER: the 8 selects after the MFMA cost more than the conflicts, which hide)
 #endif
 #ifndef SC_BWD_PK_ACC
-#define SC_BWD_PK_ACC 1  // packed per-item accumulators of d(delta) / <g, B> (16 VGPRs for 16 VALU instructions per pair-step)
+#define SC_BWD_PK_ACC 0  // 1: packed per-item accumulators of d(delta) / <g, B> (16 VGPRs for 16 VALU instructions per pair-step;
+                         // measured 1 % slower: 255 VGPRs + per-chunk spill reloads)
+#endif
+#ifndef SC_BWD_DA_MFMA
+#define SC_BWD_DA_MFMA 0
+#endif
+#ifndef SC_BWD_FLUSH_SPLIT
+#define SC_BWD_FLUSH_SPLIT 1  // the dB/dC flush (reads, MFMA, global stores) runs on the non-staging half of the workgroup
 #endif
 #ifndef SC_BWD_PREFETCH
 #define SC_BWD_PREFETCH 1
 #endif
 #define PRE_SLOT (SC_W * 64 * 16)       // bytes per vector slot (all waves)
 #define PRE_BYTES (SC_NDMA * PRE_SLOT)
+#define HS_BUF (SC_W * 64 * 2)            // floats per buffer of staged lane-boundary states
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
 #endif
@@ -87,6 +95,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     // item vectors of the next chunk travel global -> LDS by DMA one chunk ahead (16-byte vectors: bf16, 8 items)
     constexpr bool PREF = SC_BWD_PREFETCH && PACKED && VEC && SC_S * sizeof(T) == 16;
     char* pre = (char*)(accp + 2 * PK_BUF);  // [vector 0..5][wave][lane][16 bytes], behind the two slab buffers
+    // lane-boundary states of the pair being computed / staged next: [2 buffers][wave][lane] float2, behind everything else
+    float* hs_lds = (float*)((char*)(acc + (PACKED ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) + (PREF ? PRE_BYTES : 0));
     const int lane = threadIdx.x & 63;
     // selection matrix of the MFMA flush (see PK_TILE): row i = lane & 15 picks element pi(i & 7) of every piece
     u32x4 selA = {0u, 0u, 0u, 0u};
@@ -126,6 +136,35 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 
     StageRegs<T, SC_SV(SC_S)> st;
     StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
+    // Lane-boundary states (scan_common.h: LS[row][pair][k] = state entering block k, saved by the forward) travel with the
+    // B/C tile: staging thread t < 32 SC_W loads the 16 bytes of lanes 2 (t & 31), + 1 of channel t >> 5 for the pair staged
+    // next and drops them into LDS next to the tile; every wave then reads its float2 after the barrier.  Only the staging
+    // waves wait on vmcnt inside the pair loop (the other half of the workgroup issues the dB/dC flush stores instead).
+    const int64_t ls_rs = sc_ls_row(L);
+    const bool hs_on = threadIdx.x < 32 * SC_W;
+    const float* hs_src;
+    {
+        const int ew = blockIdx.x * SC_W + (threadIdx.x >> 5);
+        hs_src = a.chunk_state + ((int64_t)(ew < a.E ? ew : a.E - 1) * SB + sb) * NP * ls_rs * 2 + 4 * (threadIdx.x & 31);
+    }
+    u32x4 hs_st = {0u, 0u, 0u, 0u};
+    auto hs_issue = [&](int64_t cq, int npq) {  // states entering the lanes of chunk cq, pair npq
+        if (!hs_on) return;
+        const float* q = hs_src + ((int64_t)npq * ls_rs + ((SC_WHATIF & 16) ? 0 : cq * 64)) * 2;
+        if constexpr (VEC)
+            sc_async_load(hs_st, q);
+        else
+            hs_st = *(const u32x4*)q;
+    };
+    auto hs_store = [&](int b, bool keep_dma) {  // wait for the staged loads (tile + states), park the states in buffer b
+        if constexpr (VEC) {
+            if (threadIdx.x < 256) {
+                static_assert(sizeof(StVec<T, SC_SV(SC_S)>) <= 16, "staging vectors of the backward: 8 or 16 bytes");
+                sc_async_wait_keep3(st.s0, st.s1, hs_st, keep_dma);
+            }
+        }
+        if (hs_on) *(u32x4*)(hs_lds + b * HS_BUF + 4 * threadIdx.x) = hs_st;
+    };
     ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw, o2_raw;  // u_raw / d_raw stay in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
@@ -143,6 +182,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (o_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
             if (o2_row) sc_load_raw<T, SC_S, VEC>(o2_row, base + (int64_t)lane * SC_S, L, rev, o2_raw);
         }
+        hs_issue(nchunks - 1, 0);
+        hs_store(0, false);
         sc_stage_store<T, SC_S, VEC>(st, smem, rev);
     }
     __syncthreads();
@@ -171,23 +212,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         const float* gp = a.dhT + ((int64_t)e * SB + sb) * N + 2 * lane;
         carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
     }
-    // state entering this lane's segment, per pair: the forward saved the running state at the end of every SC_S
-    // positions (lane-boundary states, scan_common.h); block 0 of the row starts from the state at the row's start
-    // (first chunk-state slot = h0 or zero).  Loaded asynchronously one pair-step ahead, see sc_async_wait_keep1 below.
-    const int64_t ls_nblk = sc_ls_blocks(L);
-    const float* ls_base = a.chunk_state + sc_ls_offset(a.E, SB, L, N) + ((int64_t)e * SB + sb) * NP * ls_nblk * 2;
-    const float* cs0 = a.chunk_state + ((int64_t)e * SB + sb) * nchunks * NP * 2;
-    auto ls_ptr = [&](int64_t cq, int npq) {
-        const int64_t k = cq * 64 + lane;
-        return k == 0 ? cs0 + npq * 2 : ls_base + ((int64_t)npq * ls_nblk + k - 1) * 2;
-    };
-    f32x2 hs_next;
-    {
-        f32x2 fly;
-        sc_async_load(fly, ls_ptr(nchunks - 1, 0));
-        hs_next = sc_async_wait_take1(fly, false);
-    }
-    f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
+    f32x2 dAacc = f2(0.f);   // lane np: dA of pair np (d_state > 16)
+    // d_state <= 16: the cross-lane sum and the accumulation over the row run on the matrix core.  Row 2 np + s of a
+    // 16 x 16 fp32 accumulator collects pair np / state s: D += sel . B with B[k][j] = the per-lane term of lane 16 k + j and
+    // sel[i][k] = (i == 2 np + s), i.e. D[2 np + s][j] += sum_k term(16 k + j); the 16 columns are added once, at the end
+    // (2 v_mfma + 4 VALU per pair-step instead of 12 DPP adds + 2 v_readlane + 2).
+    const bool dA_mfma = SC_BWD_DA_MFMA && NP <= 8;  // (measured 5 % SLOWER than the DPP sum: off)
+    f32x4 dAmat = {0.f, 0.f, 0.f, 0.f};
     float dDacc = 0.f, dbacc = 0.f;
     int tix = 0;
 
@@ -324,11 +355,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);
-            const f32x2 h0 = hs_next;  // state entering this lane's segment (landed: waited for in the previous pair-step)
-            // the next pair-step's: issued BEFORE the tile loads / the DMA prefetch, so that the counted wait at the staging
-            // store (vmcnt retires in order) covers it in every wave
-            f32x2 hs_fly;  // (unconditional: the very last pair-step re-reads its own state)
-            sc_async_load(hs_fly, (np + 1 < NP) ? ls_ptr(c, np + 1) : ls_ptr(c > 0 ? c - 1 : 0, 0));
+            const f32x2 h0 = *(const f32x2*)(hs_lds + buf * HS_BUF + wave * 128 + lane * 2);  // state entering this lane's segment
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 } else {
                     sc_stage_load<T, SC_S, false>(st, sctx, nn, N, nb, L, rev);
                 }
+                hs_issue((np + 1 < NP) ? c : c - 1, (np + 1 < NP) ? np + 1 : 0);
             }
             // the next (earlier) chunk's item vectors: by DMA into LDS, issued behind this pair-step's tile loads (the
             // counted wait at the staging store lets them fly) and a whole chunk ahead of their use
@@ -427,17 +455,25 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }
             }
             SC_TIME(7);  // gradient loop + slab writes
-            dAp = wave_sum2_dpp(dAp);
-            if (lane == np) dAacc = dAacc + dAp * f2(keep);
+            if (dA_mfma) {  // wave-uniform
+                const int row = lane & 15;
+                dAmat = cad_mfma_16x16x4_f32(row == 2 * np ? 1.f : 0.f, dAp[0], dAmat);
+                dAmat = cad_mfma_16x16x4_f32(row == 2 * np + 1 ? 1.f : 0.f, dAp[1], dAmat);
+            } else {
+                dAp = wave_sum2_dpp(dAp);
+                if (lane == np) dAacc = dAacc + dAp * f2(keep);
+            }
             if constexpr (!PREF) {
                 // (register prefetch: the next chunk's vectors overwrite u_raw / d_raw behind this pair's barrier)
                 if (np == NP - 1) chunk_epilogue();
             }
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
-            hs_next = sc_async_wait_take1(hs_fly, dma_now);  // every wave (only waves 0..3 stage)
-            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
+            if (more) {
+                hs_store(buf ^ 1, dma_now);
+                sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
+            }
             SC_TIME(9);  // staging store (waits for the tile loads)
-            __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
+            if (!(SC_WHATIF & 2)) __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             SC_TIME(10);  // barrier wait
             if (!PREF && np == NP - 1 && c > 0) {
                 // the item vectors of the next (earlier) chunk: issued now, they land behind this pair's flush and the
@@ -454,8 +490,15 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // consecutive positions, stored 4 at a time (8/16-byte stores).  With two slab buffers the next pair writes
             // the other buffer, so one barrier per pair suffices.
             if constexpr (PACKED) {
-                // wave w sums tensor (w >> 2), lanes 16 (w & 3) .. + 15 over the 8 channels on the matrix core
-                const int ten = wave >> 2, jb = wave & 3;
+                // unit u sums tensor (u >> 2), lanes 16 (u & 3) .. + 15 over the 8 channels on the matrix core.  The units
+                // belong to the waves that do NOT stage (two each): their stores never sit in front of a vmcnt wait of the
+                // pair loop (vmcnt retires in order -- a staging wave would wait for the write acknowledgements too)
+                constexpr int FQ = SC_BWD_FLUSH_SPLIT ? 2 : 1;
+                if (!SC_BWD_FLUSH_SPLIT || wave >= SC_W / 2)
+#pragma unroll
+                for (int fq = 0; fq < FQ; ++fq) {
+                const int unit = SC_BWD_FLUSH_SPLIT ? 2 * (wave - SC_W / 2) + fq : wave;
+                const int ten = unit >> 2, jb = unit & 3;
                 const int g = lane >> 4, jl = lane & 15;
                 const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + (jb * 16 + jl) * 4 + g * (2 * PK_TILE);
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
@@ -472,7 +515,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     d0 = f32x4{d0[2], d0[3], d0[0], d0[1]};
                     d1 = f32x4{d1[2], d1[3], d1[0], d1[1]};
                 }
-                if (g < 2 && n0 + g < N) {
+                if (!(SC_WHATIF & 1) && g < 2 && n0 + g < N) {
                     const int64_t p = base + (int64_t)(jb * 16 + jl) * SC_S;
                     // row (state n0 + g) of this workgroup's slot: scalar base + one per-lane select (g is 0 or 1 here)
                     T* grow = (ten ? dCg : dBg) + ((int64_t)n0 * SB + sb) * L + (g ? SB * L : (int64_t)0);
@@ -482,11 +525,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                             if (rev) {
                                 o[0] = cad_pack_bf16x2_safe(d1[3], d1[2]), o[1] = cad_pack_bf16x2_safe(d1[1], d1[0]);
                                 o[2] = cad_pack_bf16x2_safe(d0[3], d0[2]), o[3] = cad_pack_bf16x2_safe(d0[1], d0[0]);
-                                *(u32x4*)(grow + (L - p - SC_S)) = o;
+                                sc_st16<SC_NT_STORES & 1>((u32x4_a4*)(grow + (L - p - SC_S)), o);
                             } else {
                                 o[0] = cad_pack_bf16x2_safe(d0[0], d0[1]), o[1] = cad_pack_bf16x2_safe(d0[2], d0[3]);
                                 o[2] = cad_pack_bf16x2_safe(d1[0], d1[1]), o[3] = cad_pack_bf16x2_safe(d1[2], d1[3]);
-                                *(u32x4*)(grow + p) = o;
+                                sc_st16<SC_NT_STORES & 1>((u32x4_a4*)(grow + p), o);
                             }
                         }
                     } else {
@@ -497,6 +540,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         }
                     }
                 }
+                }  // fq
             } else {
                 constexpr int QT = 64 * SC_W / 4;     // threads per (tensor, state)
                 constexpr int FT = SC_CHUNK / QT;     // positions per thread (4 or 8)
@@ -547,7 +591,18 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         if (2 * lane + 1 < N) gp[1] = carryG[1];
     }
     // per-channel parameter gradients (E x N, E: a few device-scope atomics per wave, once per kernel)
-    if (act && lane < NP) {
+    if (dA_mfma) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // lane l: column l & 15 of rows 4 (l >> 4) + r; row total -> lane 15 of each row
+            float v = dAmat[r];
+            v += dpp_row_shr<1>(0.f, v);
+            v += dpp_row_shr<2>(0.f, v);
+            v += dpp_row_shr<4>(0.f, v);
+            v += dpp_row_shr<8>(0.f, v);
+            const int n = 4 * (lane >> 4) + r;
+            if (act && (lane & 15) == 15 && n < N) atomicAdd(a.dA + e * N + n, v);
+        }
+    } else if (act && lane < NP) {
         const int n0 = 2 * lane;
         atomicAdd(a.dA + e * N + n0, dAacc[0]);
         if (n0 + 1 < N) atomicAdd(a.dA + e * N + n0 + 1, dAacc[1]);
@@ -600,32 +655,19 @@ __global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a)
             const int n0 = 2 * np;
             const bool two = n0 + 1 < N;
             const f32x2 A2 = f2(a.A[e * N + n0], two ? a.A[e * N + n0 + 1] : 0.f) * f2(CAD_LOG2E);
-            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + np) * 2;
-            const f32x2 hin = f2(stp[0], stp[1]);
+            // state entering this lane's segment (lane-boundary states of the forward)
+            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * NP + np) * sc_ls_row(L) + c * 64 + lane) * 2;
+            f32x2 h = f2(stp[0], stp[1]);
             const T* Brow = (const T*)a.Bm + ((int64_t)n0 * SB + sb) * L;
             const T* Crow = (const T*)a.Cm + ((int64_t)n0 * SB + sb) * L;
-            f32x2 av[SC_S], bv[SC_S], Cv[SC_S];
-            f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const bool ok = p0 + i < L;
                 const int64_t l = ok ? cad_phys(p0 + i, L, rev) : 0;
                 const f32x2 Bv = ok ? f2(to_f32(Brow[l]), two ? to_f32(Brow[SB * L + l]) : 0.f) : f2(0.f);
-                Cv[i] = ok ? f2(to_f32(Crow[l]), two ? to_f32(Crow[SB * L + l]) : 0.f) : f2(0.f);
-                av[i] = exp2_2(splat_lo(dd[i]) * A2);
-                bv[i] = splat_hi(dd[i]) * Bv;
-                acc_h = av[i] * acc_h + bv[i];
-                acc_a = acc_a * av[i];
-            }
-            f32x2 PA = acc_a, PH = acc_h;
-            wave_scan_fwd(PA, PH);
-            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
-            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
-            f32x2 h = ea * hin + eh;
-#pragma unroll
-            for (int i = 0; i < SC_S; ++i) {
-                h = av[i] * h + bv[i];
-                y[i] += dot2(Cv[i], h);
+                const f32x2 Cv = ok ? f2(to_f32(Crow[l]), two ? to_f32(Crow[SB * L + l]) : 0.f) : f2(0.f);
+                h = exp2_2(splat_lo(dd[i]) * A2) * h + splat_hi(dd[i]) * Bv;
+                y[i] += dot2(Cv, h);
             }
         }
 #pragma unroll
@@ -714,7 +756,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
     const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) * sizeof(float) +
-                         (pref ? PRE_BYTES : 0);
+                         (pref ? PRE_BYTES : 0) + 2 * HS_BUF * sizeof(float);
 #define SC_BWD_LAUNCH(T, V)                                                      \
     do {                                                                         \
         SC_BIG_LDS((scan_bwd_kernel<T, V>), shmem);                              \
