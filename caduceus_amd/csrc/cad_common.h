@@ -264,32 +264,6 @@ __device__ __forceinline__ f32x4 cad_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 
     return __builtin_bit_cast(f32x4, r);
 }
 #endif
-// v_mfma_f32_16x16x4_f32:  D (16 x 16) += A (16 x 4) . B (4 x 16), one fp32 element of A and of B per lane.
-// A: row i = l & 15, column k = l >> 4;  B: row k = l >> 4, column j = l & 15;  C / D: column j = l & 15, rows 4 (l >> 4) + r.
-#ifdef CAD_EMU
-__device__ __forceinline__ f32x4 cad_mfma_16x16x4_f32(float a, float b, f32x4 c) {
-    const int lane = emu::lane_id();
-    const int col = lane & 15, rg = lane >> 4;
-    f32x4 d = c;
-    float bk[4], ak[4][4];
-    for (int k = 0; k < 4; ++k) {
-        bk[k] = cad_bits2f((uint32_t)emu_exchange((uint64_t)cad_f2bits(b), k * 16 + col));
-        for (int r = 0; r < 4; ++r) ak[r][k] = cad_bits2f((uint32_t)emu_exchange((uint64_t)cad_f2bits(a), k * 16 + 4 * rg + r));
-    }
-    for (int r = 0; r < 4; ++r) {
-        float s = c[r];
-        for (int k = 0; k < 4; ++k) s += ak[r][k] * bk[k];
-        d[r] = s;
-    }
-    return d;
-}
-#else
-__device__ __forceinline__ f32x4 cad_mfma_16x16x4_f32(float a, float b, f32x4 c) {
-    typedef float f32x4_hw __attribute__((ext_vector_type(4)));
-    const f32x4_hw r = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, __builtin_bit_cast(f32x4_hw, c), 0, 0, 0);
-    return __builtin_bit_cast(f32x4, r);
-}
-#endif
 // ds_read_b64_tr_b16: transposing LDS read for 16-bit elements.  Within every 16-lane group, lane 4 r + c (r, c in 0..3)
 // supplies the address of 4 contiguous elements S[r][4c .. 4c+3] of a 4 x 16 block S; lane l of the group receives the
 // COLUMN  (S[0][l], S[1][l], S[2][l], S[3][l]).  This is how a [k][token] tile (token-contiguous, as the channel-major

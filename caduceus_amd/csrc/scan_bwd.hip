@@ -58,22 +58,11 @@ struct ScanBwdSets {
 #define SC_BWD_SLAB_SWZ 0  // 1: exchange the item pairs of a slab piece on lanes 8..15 of every 16 (no bank conflicts on the slab
                            // writes; measured 1.5 % SLOWER: the 8 selects after the MFMA cost more than the conflicts, which hide)
 #endif
-#ifndef SC_BWD_PK_ACC
-#define SC_BWD_PK_ACC 0  // 1: packed per-item accumulators of d(delta) / <g, B> (16 VGPRs for 16 VALU instructions per pair-step;
-                         // measured 1 % slower: 255 VGPRs + per-chunk spill reloads)
-#endif
-#ifndef SC_BWD_DA_MFMA
-#define SC_BWD_DA_MFMA 0
-#endif
-#ifndef SC_BWD_FLUSH_SPLIT
-#define SC_BWD_FLUSH_SPLIT 1  // the dB/dC flush (reads, MFMA, global stores) runs on the non-staging half of the workgroup
-#endif
 #ifndef SC_BWD_PREFETCH
 #define SC_BWD_PREFETCH 1
 #endif
 #define PRE_SLOT (SC_W * 64 * 16)       // bytes per vector slot (all waves)
 #define PRE_BYTES (SC_NDMA * PRE_SLOT)
-#define HS_BUF (SC_W * 64 * 2)            // floats per buffer of staged lane-boundary states
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
 #endif
@@ -95,8 +84,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     // item vectors of the next chunk travel global -> LDS by DMA one chunk ahead (16-byte vectors: bf16, 8 items)
     constexpr bool PREF = SC_BWD_PREFETCH && PACKED && VEC && SC_S * sizeof(T) == 16;
     char* pre = (char*)(accp + 2 * PK_BUF);  // [vector 0..5][wave][lane][16 bytes], behind the two slab buffers
-    // lane-boundary states of the pair being computed / staged next: [2 buffers][wave][lane] float2, behind everything else
-    float* hs_lds = (float*)((char*)(acc + (PACKED ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) + (PREF ? PRE_BYTES : 0));
     const int lane = threadIdx.x & 63;
     // selection matrix of the MFMA flush (see PK_TILE): row i = lane & 15 picks element pi(i & 7) of every piece
     u32x4 selA = {0u, 0u, 0u, 0u};
@@ -136,35 +123,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
 
     StageRegs<T, SC_SV(SC_S)> st;
     StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
-    // Lane-boundary states (scan_common.h: LS[row][pair][k] = state entering block k, saved by the forward) travel with the
-    // B/C tile: staging thread t < 32 SC_W loads the 16 bytes of lanes 2 (t & 31), + 1 of channel t >> 5 for the pair staged
-    // next and drops them into LDS next to the tile; every wave then reads its float2 after the barrier.  Only the staging
-    // waves wait on vmcnt inside the pair loop (the other half of the workgroup issues the dB/dC flush stores instead).
-    const int64_t ls_rs = sc_ls_row(L);
-    const bool hs_on = threadIdx.x < 32 * SC_W;
-    const float* hs_src;
-    {
-        const int ew = blockIdx.x * SC_W + (threadIdx.x >> 5);
-        hs_src = a.chunk_state + ((int64_t)(ew < a.E ? ew : a.E - 1) * SB + sb) * NP * ls_rs * 2 + 4 * (threadIdx.x & 31);
-    }
-    u32x4 hs_st = {0u, 0u, 0u, 0u};
-    auto hs_issue = [&](int64_t cq, int npq) {  // states entering the lanes of chunk cq, pair npq
-        if (!hs_on) return;
-        const float* q = hs_src + ((int64_t)npq * ls_rs + ((SC_WHATIF & 16) ? 0 : cq * 64)) * 2;
-        if constexpr (VEC)
-            sc_async_load(hs_st, q);
-        else
-            hs_st = *(const u32x4*)q;
-    };
-    auto hs_store = [&](int b, bool keep_dma) {  // wait for the staged loads (tile + states), park the states in buffer b
-        if constexpr (VEC) {
-            if (threadIdx.x < 256) {
-                static_assert(sizeof(StVec<T, SC_SV(SC_S)>) <= 16, "staging vectors of the backward: 8 or 16 bytes");
-                sc_async_wait_keep3(st.s0, st.s1, hs_st, keep_dma);
-            }
-        }
-        if (hs_on) *(u32x4*)(hs_lds + b * HS_BUF + 4 * threadIdx.x) = hs_st;
-    };
     ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw, o2_raw;  // u_raw / d_raw stay in registers until the chunk's epilogue
     {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
@@ -182,8 +140,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (o_row) sc_load_raw<T, SC_S, VEC>(o_row, base + (int64_t)lane * SC_S, L, rev, o_raw);
             if (o2_row) sc_load_raw<T, SC_S, VEC>(o2_row, base + (int64_t)lane * SC_S, L, rev, o2_raw);
         }
-        hs_issue(nchunks - 1, 0);
-        hs_store(0, false);
         sc_stage_store<T, SC_S, VEC>(st, smem, rev);
     }
     __syncthreads();
@@ -212,13 +168,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         const float* gp = a.dhT + ((int64_t)e * SB + sb) * N + 2 * lane;
         carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
     }
-    f32x2 dAacc = f2(0.f);   // lane np: dA of pair np (d_state > 16)
-    // d_state <= 16: the cross-lane sum and the accumulation over the row run on the matrix core.  Row 2 np + s of a
-    // 16 x 16 fp32 accumulator collects pair np / state s: D += sel . B with B[k][j] = the per-lane term of lane 16 k + j and
-    // sel[i][k] = (i == 2 np + s), i.e. D[2 np + s][j] += sum_k term(16 k + j); the 16 columns are added once, at the end
-    // (2 v_mfma + 4 VALU per pair-step instead of 12 DPP adds + 2 v_readlane + 2).
-    const bool dA_mfma = SC_BWD_DA_MFMA && NP <= 8;  // (measured 5 % SLOWER than the DPP sum: off)
-    f32x4 dAmat = {0.f, 0.f, 0.f, 0.f};
+    f32x2 hin_next = f2(0.f);
+    if (lane < NP) {
+        const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + nchunks - 1) * NP + lane) * 2;
+        hin_next = f2(stp[0], stp[1]);
+    }
+    f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
     float dDacc = 0.f, dbacc = 0.f;
     int tix = 0;
 
@@ -227,11 +182,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         const int64_t base = c * SC_CHUNK;
         const int64_t p0 = base + (int64_t)lane * SC_S;
         SC_TIME(0);  // flush tail of the previous pair-step / loop overhead
-#if SC_BWD_PK_ACC
-        f32x2 ddt[SC_S], gBs[SC_S];   // sum over the states (even / odd halves) of g * h_{i-1} * a * A  and of  <g, B>
-#else
         float ddt[SC_S], gBs[SC_S];   // sum over the states of g * h_{i-1} * a * A  and of  <g, B>
-#endif
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
@@ -297,7 +248,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         dzv[i] = dy[i] * ys * (1.f + zz[i] * (1.f - sg));
                         dy[i] *= zz[i] * sg;
                     }
-                    if (act) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
+                    if (act && !(SC_WHATIF & 2048)) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
                 } else {
 #pragma unroll
                     for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
@@ -308,27 +259,29 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 // softplus is evaluated for every lane and masked afterwards (a select, not a branch around the
                 // transcendental sequence); on the vector path all items of a lane are in or out of range together
                 const bool ok = VEC ? (p0 < L) : (p0 + i < L);
-                const float sp = cad_softplus(dt[i] + bias);
+                const float sp = (SC_WHATIF & 1024) ? dt[i] + bias : cad_softplus(dt[i] + bias);
                 const float dti = ok ? sp : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
-#if SC_BWD_PK_ACC
-                ddt[i] = f2(0.f);
-                gBs[i] = f2(0.f);
-#else
                 ddt[i] = 0.f;
                 gBs[i] = 0.f;
-#endif
                 dDacc += dyi * uu[i];
                 dd[i] = f2(dti, dti * uu[i]);
                 sum_dt += dti;
                 dy2[i >> 1][i & 1] = dyi;
             }
         }
+        // running states of all pairs at this chunk's start (saved by the forward): lane np holds pair np; the next
+        // (earlier) chunk's states are fetched now and land while this chunk computes
+        const f32x2 hin_reg = hin_next;
+        if (lane < NP && c > 0) {
+            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c - 1) * NP + lane) * 2;
+            hin_next = f2(stp[0], stp[1]);
+        }
         // per-item outputs of this chunk (all states folded in): u / delta from the raw vectors loaded at the chunk's start.
         // With the LDS-DMA prefetch nothing overwrites those registers, so it runs once BEHIND the pair loop (inside the
         // loop the compiler if-converts it and evaluates its transcendentals in every pair-step).
         auto chunk_epilogue = [&]() {
-            float uu[SC_S], dl[SC_S], du[SC_S], ddo[SC_S];
+            float uu[SC_S], dl[SC_S], du[SC_S];
             sc_unpack<T, SC_S>(u_raw, rev, uu);
             sc_unpack<T, SC_S>(d_raw, rev, dl);
 #pragma unroll
@@ -337,25 +290,19 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
                 const float dyi = dy2[i >> 1][i & 1];
                 const bool ok = VEC ? (p0 < L) : (p0 + i < L);
-#if SC_BWD_PK_ACC
-                const float gB = gBs[i][0] + gBs[i][1], dts = ddt[i][0] + ddt[i][1];
-#else
-                const float gB = gBs[i], dts = ddt[i];
-#endif
-                du[i] = dd[i][0] * gB + dyi * Dv;
-                ddo[i] = ok ? (dts + uu[i] * gB) * sg : 0.f;
-                dbacc += ddo[i];
+                du[i] = dd[i][0] * gBs[i] + dyi * Dv;
+                ddt[i] = ok ? (ddt[i] + uu[i] * gBs[i]) * sg : 0.f;
+                dbacc += ddt[i];
             }
-            if (act) {
+            if (act && !(SC_WHATIF & 2048)) {
                 sc_store<T, SC_S, VEC>(du_row, p0, L, rev, du);
-                sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddo);
+                sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
             }
         };
         SC_TIME(1);  // chunk prologue: unpack, gate, softplus
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);
-            const f32x2 h0 = *(const f32x2*)(hs_lds + buf * HS_BUF + wave * 128 + lane * 2);  // state entering this lane's segment
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
@@ -365,7 +312,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 } else {
                     sc_stage_load<T, SC_S, false>(st, sctx, nn, N, nb, L, rev);
                 }
-                hs_issue((np + 1 < NP) ? c : c - 1, (np + 1 < NP) ? np + 1 : 0);
             }
             // the next (earlier) chunk's item vectors: by DMA into LDS, issued behind this pair-step's tile loads (the
             // counted wait at the staging store lets them fly) and a whole chunk ahead of their use
@@ -380,24 +326,37 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             const int n0 = 2 * np;
             const f32x2 Av = readlane2(Areg, np);
             const f32x2 A2 = Av * f2(CAD_LOG2E);
+            const f32x2 hin = readlane2(hin_reg, np);
             // B and C of this pair are each needed twice (recompute / gradient step, reverse scan / gradient step): read
             // them from the LDS tile once, up front
             f32x2 Cv[SC_S], Bw[SC_S];
 #pragma unroll
-            for (int i = 0; i < SC_S; ++i) Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
+            for (int i = 0; i < SC_S; ++i) {
+                if (SC_WHATIF & 64)
+                    Bw[i] = f2(__builtin_bit_cast(float, lane + i)), Cv[i] = f2(__builtin_bit_cast(float, lane - i));
+                else
+                    Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
+            }
             SC_TIME(2);  // staging issue + B/C tile reads
-            // 1. forward recompute from the saved lane-boundary state h0: no serial pre-pass, no wave scan
+            // 1. forward recompute: serial totals, wave scan, then the true h_i
             f32x2 av[SC_S], hs[SC_S];
+            f32x2 acc_h = f2(0.f);
             const f32x2 acc_a = exp2_2(f2(sum_dt) * A2);  // product of the lane's a_i
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
-                av[i] = exp2_2(splat_lo(dd[i]) * A2);
+                av[i] = (SC_WHATIF & 128) ? splat_lo(dd[i]) * A2 : exp2_2(splat_lo(dd[i]) * A2);
                 hs[i] = splat_hi(dd[i]) * Bw[i];  // b_i
+                acc_h = av[i] * acc_h + hs[i];
             }
-            SC_TIME(3);  // exp
+            SC_TIME(3);  // exp + serial scan
+            f32x2 PA = acc_a, PH = acc_h;
+            if (!(SC_WHATIF & 512)) wave_scan_fwd(PA, PH);
+            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
+            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
+            const f32x2 h0 = ea * hin + eh;  // state entering this lane's segment
             // the true h_i (forward chain) and 2. the reverse scan of G (backward chain), interleaved: two independent
             // serial v_pk_fma chains, each step of one fills the wait state the other needs between dependent packed ops
-            SC_TIME(4);
+            SC_TIME(4);  // forward wave scan
             f32x2 RG = f2(0.f);
             {
                 f32x2 h = h0;
@@ -412,7 +371,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             SC_TIME(5);  // true h + lane-local reverse scan
             f32x2 QG = RG;
             const f32x2 gin = readlane2(carryG, np);
-            wave_scan_rev_carry(acc_a, QG, gin, lane);  // QG: the true G flowing out of each lane
+            if (!(SC_WHATIF & 256)) wave_scan_rev_carry(acc_a, QG, gin, lane);  // QG: the true G flowing out of each lane
             f32x2 G = f2(dpp_wave_shl1(gin[0], QG[0]), dpp_wave_shl1(gin[1], QG[1]));  // G_{i+1} for this lane's last item
             const f32x2 newc = readlane2(QG, 0);
             if (lane == np) carryG = newc;
@@ -427,13 +386,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
-#if SC_BWD_PK_ACC
-                ddt[i] = t * Av + ddt[i];  // one v_pk_fma each (the halves are added once per chunk, in the epilogue)
-                gBs[i] = g * Bv + gBs[i];
-#else
-                ddt[i] = dot2_acc(ddt[i], t, Av);  // scalar accumulators: two v_fmac each, 16 VGPRs less
-                gBs[i] = dot2_acc(gBs[i], g, Bv);
-#endif
+                ddt[i] = dot2_acc(ddt[i], t, Av);  // scalar accumulators: the packed form (one v_pk_fma each) needs 16 more
+                gBs[i] = dot2_acc(gBs[i], g, Bv);  // VGPRs, spills, and the spill traffic reaches HBM (+0.75 GB per launch)
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * SC_DY(i);
@@ -446,8 +400,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         // SC_BWD_SLAB_SWZ for the swizzle that removes them and why it is off)
                         uint32_t* qB = accp + buf * PK_BUF + wave * 2 * PK_TILE + (i >> 2) * PK_Q + lane * 4 +
                                        ((((i >> 1) ^ ((lane >> 3) & SC_BWD_SLAB_SWZ)) & 1) * 2);
-                        *(u32x2*)qB = u32x2{pB, pkB};
-                        *(u32x2*)(qB + PK_TILE) = u32x2{pC, pkC};
+                        if (!(SC_WHATIF & 32)) {
+                            *(u32x2*)qB = u32x2{pB, pkB};
+                            *(u32x2*)(qB + PK_TILE) = u32x2{pC, pkC};
+                        } else {
+                            asm volatile("" ::"v"(pB), "v"(pkB), "v"(pC), "v"(pkC));
+                        }
                     }
                 } else {
                     *(f32x2*)(aB + i * ACC_ISTR) = dBv;  // ds_write_b64, conflict-free
@@ -455,23 +413,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }
             }
             SC_TIME(7);  // gradient loop + slab writes
-            if (dA_mfma) {  // wave-uniform
-                const int row = lane & 15;
-                dAmat = cad_mfma_16x16x4_f32(row == 2 * np ? 1.f : 0.f, dAp[0], dAmat);
-                dAmat = cad_mfma_16x16x4_f32(row == 2 * np + 1 ? 1.f : 0.f, dAp[1], dAmat);
-            } else {
-                dAp = wave_sum2_dpp(dAp);
-                if (lane == np) dAacc = dAacc + dAp * f2(keep);
-            }
+            dAp = wave_sum2_dpp(dAp);
+            if (lane == np) dAacc = dAacc + dAp * f2(keep);
             if constexpr (!PREF) {
                 // (register prefetch: the next chunk's vectors overwrite u_raw / d_raw behind this pair's barrier)
                 if (np == NP - 1) chunk_epilogue();
             }
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
-            if (more) {
-                hs_store(buf ^ 1, dma_now);
-                sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
-            }
+            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
             SC_TIME(9);  // staging store (waits for the tile loads)
             if (!(SC_WHATIF & 2)) __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             SC_TIME(10);  // barrier wait
@@ -490,15 +439,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // consecutive positions, stored 4 at a time (8/16-byte stores).  With two slab buffers the next pair writes
             // the other buffer, so one barrier per pair suffices.
             if constexpr (PACKED) {
-                // unit u sums tensor (u >> 2), lanes 16 (u & 3) .. + 15 over the 8 channels on the matrix core.  The units
-                // belong to the waves that do NOT stage (two each): their stores never sit in front of a vmcnt wait of the
-                // pair loop (vmcnt retires in order -- a staging wave would wait for the write acknowledgements too)
-                constexpr int FQ = SC_BWD_FLUSH_SPLIT ? 2 : 1;
-                if (!SC_BWD_FLUSH_SPLIT || wave >= SC_W / 2)
-#pragma unroll
-                for (int fq = 0; fq < FQ; ++fq) {
-                const int unit = SC_BWD_FLUSH_SPLIT ? 2 * (wave - SC_W / 2) + fq : wave;
-                const int ten = unit >> 2, jb = unit & 3;
+                if (!(SC_WHATIF & 32)) {
+                // wave w sums tensor (w >> 2), lanes 16 (w & 3) .. + 15 over the 8 channels on the matrix core
+                const int ten = wave >> 2, jb = wave & 3;
                 const int g = lane >> 4, jl = lane & 15;
                 const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + (jb * 16 + jl) * 4 + g * (2 * PK_TILE);
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
@@ -525,11 +468,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                             if (rev) {
                                 o[0] = cad_pack_bf16x2_safe(d1[3], d1[2]), o[1] = cad_pack_bf16x2_safe(d1[1], d1[0]);
                                 o[2] = cad_pack_bf16x2_safe(d0[3], d0[2]), o[3] = cad_pack_bf16x2_safe(d0[1], d0[0]);
-                                sc_st16<SC_NT_STORES & 1>((u32x4_a4*)(grow + (L - p - SC_S)), o);
+                                *(u32x4*)(grow + (L - p - SC_S)) = o;
                             } else {
                                 o[0] = cad_pack_bf16x2_safe(d0[0], d0[1]), o[1] = cad_pack_bf16x2_safe(d0[2], d0[3]);
                                 o[2] = cad_pack_bf16x2_safe(d1[0], d1[1]), o[3] = cad_pack_bf16x2_safe(d1[2], d1[3]);
-                                sc_st16<SC_NT_STORES & 1>((u32x4_a4*)(grow + p), o);
+                                *(u32x4*)(grow + p) = o;
                             }
                         }
                     } else {
@@ -540,7 +483,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         }
                     }
                 }
-                }  // fq
+                }  // SC_WHATIF & 32
             } else {
                 constexpr int QT = 64 * SC_W / 4;     // threads per (tensor, state)
                 constexpr int FT = SC_CHUNK / QT;     // positions per thread (4 or 8)
@@ -591,18 +534,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         if (2 * lane + 1 < N) gp[1] = carryG[1];
     }
     // per-channel parameter gradients (E x N, E: a few device-scope atomics per wave, once per kernel)
-    if (dA_mfma) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {  // lane l: column l & 15 of rows 4 (l >> 4) + r; row total -> lane 15 of each row
-            float v = dAmat[r];
-            v += dpp_row_shr<1>(0.f, v);
-            v += dpp_row_shr<2>(0.f, v);
-            v += dpp_row_shr<4>(0.f, v);
-            v += dpp_row_shr<8>(0.f, v);
-            const int n = 4 * (lane >> 4) + r;
-            if (act && (lane & 15) == 15 && n < N) atomicAdd(a.dA + e * N + n, v);
-        }
-    } else if (act && lane < NP) {
+    if (act && lane < NP) {
         const int n0 = 2 * lane;
         atomicAdd(a.dA + e * N + n0, dAacc[0]);
         if (n0 + 1 < N) atomicAdd(a.dA + e * N + n0 + 1, dAacc[1]);
@@ -655,19 +587,32 @@ __global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a)
             const int n0 = 2 * np;
             const bool two = n0 + 1 < N;
             const f32x2 A2 = f2(a.A[e * N + n0], two ? a.A[e * N + n0 + 1] : 0.f) * f2(CAD_LOG2E);
-            // state entering this lane's segment (lane-boundary states of the forward)
-            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * NP + np) * sc_ls_row(L) + c * 64 + lane) * 2;
-            f32x2 h = f2(stp[0], stp[1]);
+            const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c) * NP + np) * 2;
+            const f32x2 hin = f2(stp[0], stp[1]);
             const T* Brow = (const T*)a.Bm + ((int64_t)n0 * SB + sb) * L;
             const T* Crow = (const T*)a.Cm + ((int64_t)n0 * SB + sb) * L;
+            f32x2 av[SC_S], bv[SC_S], Cv[SC_S];
+            f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const bool ok = p0 + i < L;
                 const int64_t l = ok ? cad_phys(p0 + i, L, rev) : 0;
                 const f32x2 Bv = ok ? f2(to_f32(Brow[l]), two ? to_f32(Brow[SB * L + l]) : 0.f) : f2(0.f);
-                const f32x2 Cv = ok ? f2(to_f32(Crow[l]), two ? to_f32(Crow[SB * L + l]) : 0.f) : f2(0.f);
-                h = exp2_2(splat_lo(dd[i]) * A2) * h + splat_hi(dd[i]) * Bv;
-                y[i] += dot2(Cv, h);
+                Cv[i] = ok ? f2(to_f32(Crow[l]), two ? to_f32(Crow[SB * L + l]) : 0.f) : f2(0.f);
+                av[i] = exp2_2(splat_lo(dd[i]) * A2);
+                bv[i] = splat_hi(dd[i]) * Bv;
+                acc_h = av[i] * acc_h + bv[i];
+                acc_a = acc_a * av[i];
+            }
+            f32x2 PA = acc_a, PH = acc_h;
+            wave_scan_fwd(PA, PH);
+            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
+            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
+            f32x2 h = ea * hin + eh;
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                h = av[i] * h + bv[i];
+                y[i] += dot2(Cv[i], h);
             }
         }
 #pragma unroll
@@ -756,7 +701,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
     const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) * sizeof(float) +
-                         (pref ? PRE_BYTES : 0) + 2 * HS_BUF * sizeof(float);
+                         (pref ? PRE_BYTES : 0);
 #define SC_BWD_LAUNCH(T, V)                                                      \
     do {                                                                         \
         SC_BIG_LDS((scan_bwd_kernel<T, V>), shmem);                              \

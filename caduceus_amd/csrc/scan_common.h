@@ -35,20 +35,10 @@
 #define SC_OCC 2                // register budget: waves per SIMD the kernels are compiled for
 #endif
 #define SC_STATE_STEP (64 * SC_S_BWD)   // positions between saved running states = the backward's chunk
-// Lane-boundary states: the forward saves the running state ENTERING every block of SC_S_BWD positions (= every lane
-// segment of the backward), 8 bytes per (channel row, state pair, block):  LS[row][pair][k] = state before logical position
-// k * SC_S_BWD, k = 0 .. sc_ls_blocks(L) (k = 0: the state entering the row, h0 or zero).  The backward starts every lane
-// from its true incoming state: no serial pre-pass and no forward wave scan (45 of ~350 VALU instructions per pair-step),
-// and the gate fix-up restarts a chunk from LS[64 c].  1.07 GB of HBM per scan at E 512 x 2 rows x L 131072 x N 16.
-#define SC_LS_PER_CHUNK ((64 * SC_S_FWD) / SC_S_BWD)   // blocks per forward chunk
-static inline __host__ __device__ int64_t sc_ls_blocks(int64_t L) {
-    return (L + 64 * SC_S_FWD - 1) / (64 * SC_S_FWD) * SC_LS_PER_CHUNK;
-}
-static inline __host__ __device__ int64_t sc_ls_row(int64_t L) { return sc_ls_blocks(L) + 2; }  // entries per (row, pair): 16-B rows
-// timing experiments only (wrong results): what does a mechanism cost?
+// timing experiments only (WRONG results): what does a mechanism cost?  (tools/ab_train_scan.sh over -DSC_WHATIF=... builds)
 #ifndef SC_WHATIF
-#define SC_WHATIF 0   // bit 0: no dB/dC flush stores, bit 1: no pair-step barrier (bwd), bit 2: no wait for the lane-boundary
-#endif                // state, bit 3: every B/C tile load reads chunk 0 (cache-hot), bit 4: lane states from chunk 0
+#define SC_WHATIF 0
+#endif
 #define SC_NMAX 64              // max d_state
 #define SC_MAXSETS 2
 #define SC_ROW(S) (2 * (S) + 4)        // floats per lane row of a B/C tile (S x float2 + 16 B pad -> conflict-free b128)
@@ -336,22 +326,6 @@ __device__ __forceinline__ void wave_scan_rev_carry(f32x2 A, f32x2& G, f32x2 gin
 #endif
 }
 
-// 16-byte global store, optionally non-temporal (streamed past the L2: written once, read by a later kernel)
-#ifndef SC_NT_STORES
-#define SC_NT_STORES 0   // bit 0: dB/dC partial slots, bit 1: lane-boundary states, bit 2: du / ddelta / dz / out
-#endif
-typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // (dword-aligned is all a global 16-byte access needs)
-template <int NT>
-__device__ __forceinline__ void sc_st16(u32x4_a4* p, u32x4 v) {
-#ifndef CAD_EMU
-    if constexpr (NT != 0) {
-        __builtin_nontemporal_store(v, p);
-        return;
-    }
-#endif
-    *p = v;
-}
-
 // ---- per-lane item vectors -------------------------------------------------------------------------------------------
 template <typename T, int S>
 struct __attribute__((aligned(16))) ScVec {
@@ -462,7 +436,7 @@ __device__ __forceinline__ void sc_store(T* row, int64_t p0, int64_t L, int rev,
                 u32x4 o;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = sc_rot(sc_sel(pk[q + t], pk[NW - 1 - q - t], rmask), rot);
-                sc_st16<SC_NT_STORES & 4>((u32x4_a4*)(row + l0 + 2 * q), o);
+                *(u32x4*)(row + l0 + 2 * q) = o;
             }
         }
     } else if constexpr (VEC) {
@@ -577,30 +551,6 @@ __device__ __forceinline__ void sc_async_wait_keep(V& a, V& b, bool keep_dma) {
     a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y);
 #endif
 }
-// the same waits with a third in-flight vector (16 bytes: the staged lane-boundary states of the backward)
-template <typename V>
-__device__ __forceinline__ void sc_async_wait_keep3(V& a, V& b, u32x4& c, bool keep_dma) {
-#ifndef CAD_EMU
-    static_assert(sizeof(V) == 8 || sizeof(V) == 16, "vector sizes of the prefetching kernels");
-    typedef uint32_t uw __attribute__((ext_vector_type(sizeof(V) / 4)));
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    uw x = __builtin_bit_cast(uw, a), y = __builtin_bit_cast(uw, b);
-    u4 z = __builtin_bit_cast(u4, c);
-    const uint32_t k = __builtin_amdgcn_readfirstlane(keep_dma ? 1u : 0u);
-    asm volatile(
-        "s_cmp_eq_u32 %3, 0\n\t"
-        "s_cbranch_scc1 .Lsc_wait0_%=\n\t"
-        "s_waitcnt vmcnt(6)\n\t"
-        "s_branch .Lsc_waitd_%=\n"
-        ".Lsc_wait0_%=:\n\t"
-        "s_waitcnt vmcnt(0)\n"
-        ".Lsc_waitd_%=:"
-        : "+v"(x), "+v"(y), "+v"(z)
-        : "s"(k)
-        : "memory", "scc");
-    a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y), c = __builtin_bit_cast(u32x4, z);
-#endif
-}
 static_assert(SC_NDMA == 6, "the immediate of s_waitcnt vmcnt(6) above");
 
 // ---- LDS-DMA prefetch of the per-chunk item vectors -------------------------------------------------------------------
@@ -667,7 +617,7 @@ __device__ __forceinline__ void sc_stage_seek(StageCtx<T>& c, int64_t base, int6
     constexpr int SV = SC_SV(S);
     const int64_t p0 = base + c.tok;
     c.in = p0 < L;
-    c.cur = c.src + ((SC_WHATIF & 8) ? (int64_t)c.tok : (c.in ? (rev ? (L - p0 - SV) : p0) : 0));
+    c.cur = c.src + (c.in ? (rev ? (L - p0 - SV) : p0) : 0);
 }
 template <typename T, int S>
 __device__ __forceinline__ void sc_stage_issue(StageRegs<T, SC_SV(S)>& r, const StageCtx<T>& c, int n0, int N) {

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     constexpr int RING = SC_RING_FWD, AHEAD = RING / 2;
     static_assert(RING >= 2 && (RING & (RING - 1)) == 0, "ring of 2^k tiles");
+    constexpr int SLOTS = SC_CHUNK / SC_STATE_STEP;  // saved-state slots per forward chunk (1 or 2)
     const cad_scan_args& a = sets.s[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const float Dv = a.D ? a.D[e] : 0.f;
     const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
+    const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
     constexpr bool PREF = SC_FWD_DMA && VEC && SC_S * sizeof(T) == 32;
     char* pre = (char*)(smem + RING * 2 * TILE);  // behind the tile ring
     const uint32_t pre_lds = cad_uniform((int)(sc_lds_off(pre) + wave * (64 * 16)));
@@ -136,11 +138,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         const int n0 = 2 * lane;
         Areg = f2(a.A[e * N + n0] * CAD_LOG2E, (n0 + 1 < N) ? a.A[e * N + n0 + 1] * CAD_LOG2E : 0.f);
     }
-    // lane-boundary states for the backward (scan_common.h: LS[row][pair][k], the state entering block k)
-    static_assert(SC_S_FWD == SC_S_BWD || SC_S_FWD == 2 * SC_S_BWD, "one or two backward lane segments per forward lane");
-    constexpr int LSR = SC_S_FWD / SC_S_BWD;
-    const int64_t ls_rs = sc_ls_row(L);
-    float* ls_row = (a.chunk_state && act) ? a.chunk_state + ((int64_t)e * SB + sb) * NP * ls_rs * 2 : nullptr;
     int tix = 0;            // tiles consumed so far: tile tix lives in LDS buffer tix & 1
     SC_TIME_DECL;
     for (int64_t c = 0; c < nchunks; ++c) {
@@ -182,6 +179,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) sdt += dd[i][0];
         }
+        // running state at this chunk's start (first slot of the chunk); a mid-chunk state (second slot) is written per pair
+        float* st_base = a.chunk_state ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + SLOTS * c) * NP * 2 : nullptr;
+        if (st_base && act && lane < NP) {
+            st_base[lane * 2] = carry[0];
+            st_base[lane * 2 + 1] = carry[1];
+        }
         SC_TIME(1);  // chunk prologue: loads, unpack, softplus
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & (RING - 1);
@@ -217,34 +220,29 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             // (iii) carry in / out
             const f32x2 hin = readlane2(carry, np);
             const f32x2 h0 = ea * hin + eh;
+            // state entering lane 32 = state at logical position base + 512: the backward's half-chunk start
+            if (SLOTS == 2 && st_base && act && base + SC_STATE_STEP < L) {
+                const f32x2 mid = readlane2(h0, SC_STATE_STEP / SC_S);
+                if (lane == 0) {
+                    st_base[(NP + np) * 2] = mid[0];
+                    st_base[(NP + np) * 2 + 1] = mid[1];
+                }
+            }
             const f32x2 newc = readlane2(PA * hin + PH, 63);
             if (lane == np) carry = newc;
             SC_TIME(3);  // wave scan + carry
             cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
-            f32x2 lsv[LSR];
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
                 const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
                 const f32x4 c4 = *(const f32x4*)(tC + 2 * i);
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
-                if ((i + 2) % SC_S_BWD == 0) lsv[(i + 1) / SC_S_BWD] = hB;  // state at the end of a backward lane segment
             }
             SC_TIME(4);  // output phase (C tile reads)
             if (more) {
                 sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev, dma_now);
                 SC_FWD_ADVANCE();
-            }
-            // lane-boundary states: stored BEHIND the staging wait (vmcnt retires in order: issued before it, the store's
-            // write acknowledgement would be waited for every pair-step -- +0.12 ms per launch)
-            if (ls_row) {  // wave-uniform
-                typedef f32x2 f32x2_a8 __attribute__((aligned(8)));
-                float* q = ls_row + ((int64_t)np * ls_rs + c * SC_LS_PER_CHUNK + (int64_t)lane * LSR + 1) * 2;
-                if constexpr (LSR == 2)
-                    sc_st16<SC_NT_STORES & 2>((u32x4_a4*)q, __builtin_bit_cast(u32x4, f32x4{lsv[0][0], lsv[0][1], lsv[1][0], lsv[1][1]}));
-                else
-                    *(f32x2_a8*)q = lsv[0];
-                if (c == 0 && lane == 0) *(f32x2_a8*)(ls_row + (int64_t)np * ls_rs * 2) = hin;  // the state entering the row
             }
             SC_TIME(5);  // staging store
             if (((tix + 1) & (AHEAD - 1)) == 0) __syncthreads();
@@ -288,7 +286,8 @@ static_assert(SC_CHUNK == SC_STATE_STEP || SC_CHUNK == 2 * SC_STATE_STEP, "forwa
 extern "C" int64_t cad_scan_chunk_len(void) { return SC_CHUNK; }
 
 extern "C" int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N) {
-    return (int64_t)E * SB * ((N + 1) / 2) * sc_ls_row(L) * 2;  // lane-boundary states (scan_common.h)
+    const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
+    return (int64_t)E * SB * (nslots + 1) * ((N + 1) / 2) * 2;
 }
 
 extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream) {
