@@ -130,6 +130,7 @@ SYMBOLS = {
     "cad_proj_supported": (_i, [_i]),
     "cad_proj_wx": (_i, [C.POINTER(ProjArgs), _p]),
     "cad_proj_wx_supported": (_i, [_i, _i64]),
+    "cad_proj_wx_thin_supported": (_i, [_i, _i, _i64]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_lm_head_partials": (_i64, [_i64]),
     "cad_tokenize_mlm": (_i, [C.POINTER(MlmArgs), _p]),

@@ -308,6 +308,116 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wx_kernel(cad_proj_args
     }
 }
 
+
+// ---- cad_proj_wx, thin M / deep K:  out (M <= 64, T) = W (M, K) . X (K, T),  K a multiple of 64 -----------------------------
+// x_proj (M = dt_rank + 2 d_state, K = d_inner) and d(dt_lr) = W_dt^T . d(delta) (M = dt_rank): the streaming operand is the
+// (K, T) channel-major activation, read exactly once; W (<= 64 x K) lives in LDS for the whole launch.  A workgroup owns blocks of
+// 128 tokens (one 16-token column per wave) and walks K in chunks of 64 rows through a RING of 4 LDS tiles filled by LDS-DMA
+// three chunks ahead (counted s_waitcnt: vmcnt retires in order, two DMA instructions per wave and chunk); A fragments by
+// transposing reads as above, B fragments (W) by ds_read_b128 from the padded LDS copy, fp32 accumulation over the whole K in
+// the MFMA accumulators, 8-byte stores of four consecutive tokens per lane (the output is 1/10 of the traffic).
+struct GtCfg {
+    static constexpr int NT = 128, KC = 64, RING = 4;
+    static constexpr int XROW = NT * 2;               // bytes per tile row
+    static constexpr int XBUF = KC * XROW;            // 16 KB per chunk
+    static constexpr int DPW = (KC * NT * 2 / 16 / 64) / GP_WAVES;  // DMA instructions per wave and chunk (= 2)
+    static constexpr size_t lds(int M, int K) { return (size_t)RING * XBUF + (size_t)((M + 15) / 16 * 16) * (K * 2 + 16); }
+};
+static_assert(GtCfg::DPW == 2, "the counted waits below assume two DMA instructions per wave and chunk");
+
+__device__ __forceinline__ void gt_issue_chunk(const bf16_t* X, int64_t ldx, int k0, int64_t t0, int64_t T, char* xbuf, int wave,
+                                               int lane) {
+#pragma unroll
+    for (int i = 0; i < GtCfg::DPW; ++i) {
+        const int ins = wave * GtCfg::DPW + i;       // 16 instructions of 64 pieces: 4 tile rows each
+        const int p = ins * 64 + lane;
+        const int row = p >> 4, pp = p & 15;                         // tile row, PHYSICAL 16-byte piece
+        const int lp = (((pp >> 1) ^ gx_swz(row)) << 1) | (pp & 1);  // logical piece = 8 tokens
+        int64_t tok = t0 + lp * 8;
+        tok = tok + 8 <= T ? tok : T - 8;                            // tail block: valid data, never stored
+        cad_glds16(X + (int64_t)(k0 + row) * ldx + tok, cad_uniform((int)(cad_lds_off(xbuf) + ins * 1024)));
+    }
+}
+
+template <int MB>
+__global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj_args a) {
+    typedef GtCfg C;
+    CAD_DYN_SMEM(char, smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const int g = lane >> 4, jl = lane & 15;
+    const bf16_t* W = (const bf16_t*)a.W;
+    const bf16_t* X = (const bf16_t*)a.X;
+    bf16_t* out = (bf16_t*)a.out;
+    const int64_t T = a.T;
+    const int M = a.M, K = a.K;
+    const int NCH = K / C::KC;
+    const int64_t nblk = (T + C::NT - 1) / C::NT;
+    const int64_t b0 = blockIdx.x, bstep = gridDim.x;
+    if (b0 >= nblk) return;
+    const int64_t nmine = (nblk - b0 + bstep - 1) / bstep;
+    const int64_t total = nmine * NCH;               // (block, chunk) iterations of this workgroup
+    char* wl = smem + C::RING * C::XBUF;             // W copy: row stride WSTR (padded: the 16 rows of a B fragment read spread over the banks)
+    const int WSTR = K * 2 + 16;
+    auto issue = [&](int64_t it) {
+        const int64_t blk = b0 + (it / NCH) * bstep;
+        gt_issue_chunk(X, a.ldx, (int)(it % NCH) * C::KC, blk * C::NT, T, smem + (int)(it % C::RING) * C::XBUF, wave, lane);
+    };
+    for (int64_t it = 0; it < C::RING - 1; ++it)
+        if (it < total) issue(it);
+    // W -> LDS (rows >= M zero)
+    for (int i = threadIdx.x; i < MB * 16 * (K / 8); i += 64 * GP_WAVES) {
+        const int m = i / (K / 8), c8 = i % (K / 8);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < M) v = *(const u32x4*)(W + (int64_t)m * a.ldw + c8 * 8);
+        *(u32x4*)(wl + m * WSTR + c8 * 16) = v;
+    }
+    f32x4 d[MB];
+    for (int64_t it = 0; it < total; ++it) {
+        const int ch = (int)(it % NCH);
+        // chunk `it` has landed: of this wave's DMA, at most the two later chunks (4 instructions) may still be in flight --
+        // fewer near the end of the stream, where everything is waited for
+#ifndef CAD_EMU
+        if (it + C::RING - 2 < total)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();  // every wave's share of the chunk is visible; the tile consumed LAST iteration is free again
+        if (it + C::RING - 1 < total) issue(it + C::RING - 1);
+        if (ch == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const char* xt = smem + (int)(it % C::RING) * C::XBUF;
+#pragma unroll
+        for (int ks = 0; ks < C::KC / 32; ++ks) {
+            const int r0 = ks * 32 + g * 8 + (jl >> 2);
+            const char* p0 = xt + r0 * C::XROW + ((wave ^ gx_swz(r0)) * 32) + (jl & 3) * 8;
+            const char* p1 = xt + (r0 + 4) * C::XROW + ((wave ^ gx_swz(r0 + 4)) * 32) + (jl & 3) * 8;
+            const u32x2 lo = cad_lds_read_tr16(p0), hi = cad_lds_read_tr16(p1);
+            const u32x4 xf = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const u32x4 wf = *(const u32x4*)(wl + (mb * 16 + jl) * WSTR + (ch * C::KC + ks * 32 + g * 8) * 2);
+                d[mb] = cad_mfma_16x16x32_bf16(xf, wf, d[mb]);
+            }
+        }
+        if (ch == NCH - 1) {
+            const int64_t blk = b0 + (it / NCH) * bstep;
+            const int64_t t = blk * C::NT + wave * 16 + g * 4;  // this lane's four consecutive tokens
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mb * 16 + jl;
+                u32x2 pk;
+                pk[0] = cad_pack_bf16x2_safe(d[mb][0], d[mb][1]);
+                pk[1] = cad_pack_bf16x2_safe(d[mb][2], d[mb][3]);
+                if (m < M && t + 4 <= T) *(u32x2*)(out + (int64_t)m * a.ldo + t) = pk;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // more than 64 KB of dynamic LDS has to be requested per kernel (once)
@@ -378,9 +488,38 @@ static int launch_wx(const cad_proj_args* a, void* stream) {
 }
 
 extern "C" int cad_proj_wx_supported(int K, int64_t T) { return K >= 8 && K <= 64 && (K % 8) == 0 && T >= 8 && (T % 8) == 0; }
+// thin M / deep K variant (x_proj, d(dt_lr)): M <= 64 output rows, K a multiple of 64 up to 1024, no addend
+extern "C" int cad_proj_wx_thin_supported(int M, int K, int64_t T) {
+    return M >= 1 && M <= 64 && K > 64 && K <= 1024 && (K % 64) == 0 && T >= 8 && (T % 8) == 0 &&
+           GtCfg::lds(M, K) <= 160 * 1024;
+}
+
+template <int MB>
+static int launch_wx_thin(const cad_proj_args* a, void* stream) {
+    const int64_t nblk = (a->T + GtCfg::NT - 1) / GtCfg::NT;
+    int64_t gx = 256;  // one workgroup per CU
+    if (gx > nblk) gx = nblk;
+    const size_t lds = GtCfg::lds(MB * 16, a->K);
+    dim3 grid((unsigned)gx), block(64 * GP_WAVES);
+    GP_BIG_LDS((proj_wx_thin_kernel<MB>), lds);
+    CAD_LAUNCH((proj_wx_thin_kernel<MB>), grid, block, lds, stream, *a);
+    return cad_after_launch();
+}
 
 extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
     CAD_CHECK_ARG(a && a->W && a->X && a->out && a->T > 0 && a->M > 0 && a->K > 0);
+    if (a->acc == nullptr && cad_proj_wx_thin_supported(a->M, a->K, a->T)) {
+        CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T);
+        CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 4) == 0);
+        CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X) % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
+        CadProfScope prof(8, stream);
+        switch ((a->M + 15) / 16) {
+            case 1: return launch_wx_thin<1>(a, stream);
+            case 2: return launch_wx_thin<2>(a, stream);
+            case 3: return launch_wx_thin<3>(a, stream);
+            default: return launch_wx_thin<4>(a, stream);
+        }
+    }
     if (!cad_proj_wx_supported(a->K, a->T)) return CAD_ERR_UNSUPPORTED;
     CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T && (a->acc == nullptr || a->ldacc >= a->T));
     CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 8) == 0 && (a->ldacc % 8) == 0);

@@ -174,7 +174,10 @@ class BiMambaMixerFn(torch.autograd.Function):
             wf, bf = cparams[i]
             xc = xcs[i]
             w_x, w_dt = (cache["w"][2 + 2 * i], cache["w"][3 + 2 * i]) if cache else (W_x.to(act), W_dt.to(act))
-            dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
+            if ops.proj_wx_supported(xc, E, T, M=R + 2 * N):  # thin-M / deep-K MFMA kernel: xc read once, W_x in LDS
+                dbc = ops.proj_wx(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
+            else:
+                dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
             if ops.proj_wx_supported(xc, R, T):  # thin-K MFMA kernel (transposing LDS reads), csrc/gemm.hip
                 delta = ops.proj_wx(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
             else:
@@ -275,7 +278,10 @@ class BiMambaMixerFn(torch.autograd.Function):
                     "cad_reduce_partials")
             L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
                     "cad_reduce_partials")
-            torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+            if ops.proj_wx_supported(ddelta, E, T, M=R):
+                ops.proj_wx(w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+            else:
+                torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
             dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
             # d(xc) = du + W_x^T . d(dbc), in place (no copy of the 268 MB addend)

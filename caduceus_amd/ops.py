@@ -468,8 +468,14 @@ def proj_wxT(W: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = Non
     return out
 
 
-def proj_wx_supported(t: torch.Tensor, K: int, T: int) -> bool:
-    return t.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_wx_supported(int(K), int(T)))
+def proj_wx_supported(t: torch.Tensor, K: int, T: int, M: Optional[int] = None) -> bool:
+    """thin K (K <= 64, any M, optional addend), or -- when M is given -- thin M / deep K (M <= 64, K % 64 == 0, no addend)"""
+    if t.dtype != torch.bfloat16:
+        return False
+    lib = L.get_lib()
+    if lib.cad_proj_wx_supported(int(K), int(T)):
+        return True
+    return M is not None and bool(lib.cad_proj_wx_thin_supported(int(M), int(K), int(T)))
 
 
 def proj_wx(W: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None,

@@ -326,6 +326,9 @@ int cad_proj_supported(int K);
  * of LDS (ds_read_b64_tr_b16). */
 int cad_proj_wx(const cad_proj_args* a, void* stream);
 int cad_proj_wx_supported(int K, int64_t T);
+/* cad_proj_wx also takes thin M / deep K products without addend (M <= 64, K a multiple of 64 up to 1024, T % 8 == 0; ldo % 4):
+ * x_proj (M = dt_rank + 2 d_state, K = d_inner; `x_proj` inside mamba_inner_fn) and d(dt_lr) = W_dt^T . d(delta). */
+int cad_proj_wx_thin_supported(int M, int K, int64_t T);
 
 /* ---------------------------------------------------------------------------------------------------------
  * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()

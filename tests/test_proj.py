@@ -64,3 +64,23 @@ def test_proj_wx(backend, M, K, T, acc):
         buf = A.clone().to(dev)
         ops.proj_wx(W.to(dev), X.to(dev), out=buf, acc=buf)
         assert torch.equal(buf.cpu(), out.cpu())
+
+
+@pytest.mark.parametrize("M,K,T", [(48, 512, 384), (16, 512, 200), (33, 128, 136), (64, 256, 1032), (5, 192, 64)])
+def test_proj_wx_thin_m_deep_k(backend, M, K, T):
+    """x_proj / d(dt_lr): thin M, K walked in 64-row chunks through the DMA ring, several 128-token blocks per workgroup."""
+    name, dev = backend
+    assert ops.proj_wx_supported(_bf(1).to(dev), K, T, M=M)
+    W, X = _bf(M, K, seed=21) * 0.2, _bf(K, T, seed=22)
+    out = ops.proj_wx(W.to(dev), X.to(dev))
+    ref = W.float() @ X.float()
+    assert out.shape == (M, T)
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 4)
+    # strided output rows (the x_proj gradient operand is assembled in place) and position independence
+    buf = torch.zeros(M + 3, T + 8, dtype=torch.bfloat16, device=dev)
+    ops.proj_wx(W.to(dev), X.to(dev), out=buf[1:M + 1, :T])
+    assert torch.equal(buf[1:M + 1, :T].cpu(), out.cpu()) and float(buf[0].abs().max()) == 0 and float(buf[:, T:].abs().max()) == 0
+    perm = torch.randperm(T // 8, generator=torch.Generator().manual_seed(3))
+    Xp = X.view(K, T // 8, 8)[:, perm].reshape(K, T).contiguous()
+    outp = ops.proj_wx(W.to(dev), Xp.to(dev))
+    assert torch.equal(outp.view(M, T // 8, 8).cpu(), out.view(M, T // 8, 8)[:, perm].cpu())

@@ -69,3 +69,21 @@ for name, W, X, acc in (("dt_proj W(512x16) . dt_lr(16xT)", w_dt, dt_lr, None),
                  "hipblaslt_GBps": round(by / t_lib / 1e6, 1), "max_abs_diff_vs_hipblaslt": err}
     print(name, res[name])
 print(json.dumps(res))
+
+# thin M / deep K (x_proj forward, d(dt_lr) of the backward): the (K, T) activation is the stream
+xc, ddelta = r(E, T), r(E, T)
+w_x, w_dtT = r(R + 2 * N, E) * 0.06, (r(E, R) * 0.2).t().contiguous()
+for name, W, X in (("x_proj W_x(48x512) . xc(512xT)", w_x, xc), ("d(dt_lr) W_dt^T(16x512) . ddelta(512xT)", w_dtT, ddelta)):
+    M, K = W.shape
+    if not ops.proj_wx_supported(X, K, T, M=M):
+        continue
+    ours = ops.proj_wx(W, X)
+    ref = torch.mm(W, X)
+    err = float((ours.float() - ref.float()).abs().max())
+    t_ours = timeit(lambda: ops.proj_wx(W, X))
+    t_lib = timeit(lambda: torch.mm(W, X))
+    by = (T * K + M * K + M * T) * 2
+    res[name] = {"ours_ms": round(t_ours, 4), "hipblaslt_ms": round(t_lib, 4), "ours_GBps": round(by / t_ours / 1e6, 1),
+                 "hipblaslt_GBps": round(by / t_lib / 1e6, 1), "max_abs_diff_vs_hipblaslt": err}
+    print(name, res[name])
+print(json.dumps(res))
