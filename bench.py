@@ -251,20 +251,25 @@ def main():
             Tt = (2 if args.model == "ps" else 1) * args.batch * args.seqlen
             xx = torch.randn(Tt, args.d_model, device=dev, dtype=amp)
             ww = torch.randn(2 * E, args.d_model, device=dev, dtype=amp)
+            from caduceus_amd import ops as _ops
+            own = _ops.proj_supported(xx, args.d_model)  # the product path of the mixer (csrc/gemm.hip), else hipBLASLt
+            run = (lambda: _ops.proj_wxT(ww, xx)) if own else (lambda: torch.mm(ww, xx.t()))
             for _ in range(3):
-                torch.mm(ww, xx.t())
+                run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                torch.mm(ww, xx.t())
+                run()
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 10
             fl = 2.0 * Tt * args.d_model * 2 * E
             by = (Tt * args.d_model + 2 * E * args.d_model + Tt * 2 * E) * (2 if args.dtype == "bf16" else 4)
-            proj = {"kernel": "in_proj GEMM (hipBLASLt, MFMA)", "ms": ms, "TFLOPs": fl / ms / 1e9,
-                    "mfma_peak_TFLOPs": 2500.0 if args.dtype == "bf16" else 157.3, "GBps": by / ms / 1e6,
-                    "note": "K = d_model = 256: the GEMM is HBM-bound (arithmetic intensity ~200 flop/B), not MFMA-bound"}
+            proj = {"kernel": "in_proj GEMM (" + ("cad_proj_wxT, own bf16 MFMA kernel" if own else "hipBLASLt") + ")", "ms": ms,
+                    "TFLOPs": fl / ms / 1e9, "mfma_peak_TFLOPs": 2500.0 if args.dtype == "bf16" else 157.3,
+                    "GBps": by / ms / 1e6, "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS,
+                    "note": "K = d_model: HBM-bound (arithmetic intensity ~200 flop/B), not MFMA-bound; MFMA-busy counters "
+                            "in profiles/r02_proj_pmc_summary.txt"}
             del xx, ww
         except Exception as ex:  # evidence only
             proj = {"error": repr(ex)}
