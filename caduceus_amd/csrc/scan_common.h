@@ -667,6 +667,7 @@ __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float*
         else
             sc_async_wait(r.s0, r.s1);
     }
+    if (SC_WHATIF & 4096) return;  // (timing experiment: no conversion / LDS stores of the staged tile)
     float* tile = tiles + (t >> 7) * SC_TILE(S);
     const int tok = (t & 127) * SV;  // position inside the chunk
     float* dst = tile + (tok / S) * SC_ROW(S) + (tok % S) * 2;

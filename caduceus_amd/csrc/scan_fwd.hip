@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         for (int i = 0; i < SC_S; ++i) {
             // evaluated for every lane, masked afterwards: a select instead of a branch around the transcendentals of every
             // item (on the vector path a lane's items are in or out of range together)
-            const float sp = cad_softplus(dt[i] + bias);
+            const float sp = (SC_WHATIF & 1024) ? dt[i] + bias : cad_softplus(dt[i] + bias);
             const float dti = (VEC ? (p0 < L) : (p0 + i < L)) ? sp : 0.f;
             y2[i] = f2(Dv * du[i], 0.f);
             dd[i] = f2(dti, dti * du[i]);
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             f32x2 ha[SC_S], hh[SC_S];
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
-                const f32x2 av = exp2_2(splat_lo(dd[i]) * A2);
-                const f32x2 bv = splat_hi(dd[i]) * ld2(tB + 2 * i);
+                const f32x2 av = (SC_WHATIF & 128) ? splat_lo(dd[i]) * A2 : exp2_2(splat_lo(dd[i]) * A2);
+                const f32x2 bv = splat_hi(dd[i]) * ((SC_WHATIF & 64) ? f2(__builtin_bit_cast(float, lane + i)) : ld2(tB + 2 * i));
                 acc_h = av * acc_h + bv;
                 acc_a = acc_a * av;
                 ha[i] = acc_a;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             SC_TIME(2);  // staging issue + exp + serial scan (B tile reads)
             // (ii) inclusive scan of the affine maps across lanes (DPP)
             f32x2 PA = acc_a, PH = acc_h;
-            wave_scan_fwd(PA, PH);
+            if (!(SC_WHATIF & 512)) wave_scan_fwd(PA, PH);
             const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
             const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
             // (iii) carry in / out
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
                 const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
-                const f32x4 c4 = *(const f32x4*)(tC + 2 * i);
+                const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]} : *(const f32x4*)(tC + 2 * i);
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
             }
@@ -260,9 +260,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #endif
             sc_unpack<T, SC_S>(z_raw, rev, zz);
 #pragma unroll
-            for (int i = 0; i < SC_S; ++i) y[i] *= zz[i] * cad_sigmoid(zz[i]);
+            for (int i = 0; i < SC_S; ++i) y[i] *= (SC_WHATIF & 1024) ? zz[i] : zz[i] * cad_sigmoid(zz[i]);
         }
-        if (act) sc_store<T, SC_S, VEC>(o_row, p0, L, rev, y);
+        if (act && !(SC_WHATIF & 2048)) sc_store<T, SC_S, VEC>(o_row, p0, L, rev, y);
     }
     if (a.hT && act && lane < NP) {
         float* hp = a.hT + ((int64_t)e * SB + sb) * N + 2 * lane;
