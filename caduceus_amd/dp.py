@@ -47,6 +47,8 @@ class BucketedGradReducer:
                 cur, cur_bytes = [], 0
         if cur:
             groups.append(cur)
+        self._groups = groups
+        self._views = {}
         for bi, grp in enumerate(groups):
             n = sum(p.numel() for p in grp)
             flat = torch.zeros(n, dtype=torch.float32, device=grp[0].device)
@@ -54,54 +56,75 @@ class BucketedGradReducer:
             for p in grp:
                 if p.dtype != torch.float32:
                     raise TypeError("master parameters are expected in fp32")
-                p.grad = flat[off:off + p.numel()].view_as(p)  # gradient lives inside the bucket
+                self._views[id(p)] = flat[off:off + p.numel()].view_as(p)  # the gradient's home inside the bucket
+                p.grad = self._views[id(p)]
                 off += p.numel()
                 self._bucket_of[id(p)] = bi
                 p.register_post_accumulate_grad_hook(self._hook)
             self.buckets.append(flat)
         self._sizes = [len(g) for g in groups]
-        # (bucket, element offset) of every parameter, for re-attaching a gradient autograd replaced
-        self._slot = {}
-        for bi, grp in enumerate(groups):
-            off = 0
-            for p in grp:
-                self._slot[id(p)] = (bi, off)
-                off += p.numel()
         self._reset_counters()
 
     def _reset_counters(self):
         self._pending = list(self._sizes)
         self._handles = [None] * len(self.buckets)
 
-    def _hook(self, p: torch.nn.Parameter):
-        bi, off = self._slot[id(p)]
+    def _gather(self, bi: int):
+        """Bring the gradients autograd left OUTSIDE the bucket (p.grad was None: autograd assigned its own tensor) into
+        their views with one multi-tensor launch per bucket, instead of one accumulate kernel per parameter."""
+        srcs, dsts, stale = [], [], []
+        for p in self._groups[bi]:
+            view = self._views[id(p)]
+            g = p.grad
+            if g is None:
+                stale.append(view)          # parameter without gradient this step
+            elif g.data_ptr() != view.data_ptr():
+                srcs.append(g)
+                dsts.append(view)
+        # a gradient found outside the bucket means p.grad was None before this backward (zero_grad() below, or the caller's
+        # zero_grad(set_to_none=True)): it REPLACES the view's content; accumulation micro-steps never get here, autograd
+        # adds into the view in place
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+        if stale:
+            torch._foreach_zero_(stale)
+        for p in self._groups[bi]:
+            p.grad = self._views[id(p)]
+
+    def _launch(self, bi: int):
         flat = self.buckets[bi]
-        if p.grad.data_ptr() < flat.data_ptr() or p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * 4:
-            # autograd replaced .grad (e.g. after zero_grad(set_to_none=True)): copy back into the bucket view
-            view = flat[off:off + p.numel()].view_as(p)
-            view.copy_(p.grad)
-            p.grad = view
+        if self.average:
+            flat.div_(self.world)
+        self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _hook(self, p: torch.nn.Parameter):
+        bi = self._bucket_of[id(p)]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.sync_enabled and (self.world > 1 or self._force):
-            if self.average:
-                flat.div_(self.world)
-            self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self._pending[bi] == 0:
+            self._gather(bi)
+            if self.sync_enabled and (self.world > 1 or self._force):
+                self._launch(bi)
 
     def finish(self):
-        """Call after backward: waits for the outstanding all-reduces (and launches any that never triggered)."""
+        """Call after backward: gathers the buckets whose last gradient never arrived (unused parameters), waits for the
+        outstanding all-reduces (and launches any that never triggered)."""
+        for bi in range(len(self.buckets)):
+            if self._pending[bi] != 0:
+                self._gather(bi)
         if self.sync_enabled and (self.world > 1 or self._force):
-            for bi, flat in enumerate(self.buckets):
+            for bi in range(len(self.buckets)):
                 if self._handles[bi] is None:
-                    if self.average:
-                        flat.div_(self.world)
-                    self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._launch(bi)
             for h in self._handles:
                 h.wait()
         self._reset_counters()
 
     def zero_grad(self):
-        for flat in self.buckets:
-            flat.zero_()
+        """Start a new accumulation: gradients are detached from the buckets (p.grad = None), so autograd hands over its own
+        tensors and the next gather OVERWRITES the bucket -- no zero-fill, no per-parameter accumulate kernels."""
+        for grp in self._groups:
+            for p in grp:
+                p.grad = None
 
     class _NoSync:
         def __init__(self, r):
