@@ -62,7 +62,7 @@ class ScanArgs(C.Structure):
     _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
                 ("delta_bias", _p), ("out", _p), ("chunk_state", _p), ("SB", _i64), ("L", _i64), ("split", _i64),
                 ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i), ("h0", _p), ("hT", _p),
-                ("sum_dt", _p)]
+                ("sum_dt", _p), ("delta_is_dt", _i)]
 
 
 class ScanBwdArgs(C.Structure):
@@ -71,7 +71,7 @@ class ScanBwdArgs(C.Structure):
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
                 ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p), ("gate_fix_list", _p), ("gate_fix_count", _p),
-                ("gate_fix_dz", _p)]
+                ("gate_fix_dz", _p), ("delta_is_dt", _i)]
 
 
 class ScanTmArgs(C.Structure):
@@ -89,7 +89,7 @@ class MlmArgs(C.Structure):
 
 class ProjArgs(C.Structure):
     _fields_ = [("W", _p), ("X", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
-                ("ldo", _i64), ("acc", _p), ("ldacc", _i64)]
+                ("ldo", _i64), ("acc", _p), ("ldacc", _i64), ("bias", _p), ("act", _i)]
 
 
 class LmHeadArgs(C.Structure):

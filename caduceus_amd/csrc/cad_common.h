@@ -154,6 +154,12 @@ __device__ __forceinline__ float cad_softplus(float x) {
     return (x > 20.0f) ? x : sp;
 }
 __device__ __forceinline__ float cad_sigmoid(float x) { return cad_rcp(1.0f + cad_exp(-x)); }
+// sigmoid(x) recovered from sp = softplus(x):  1 - exp(-sp)  (series below 1/16: no cancellation for tiny sp)
+__device__ __forceinline__ float cad_sigmoid_from_softplus(float sp) {
+    const float poly = sp * (1.0f - sp * (0.5f - sp * (0.16666667f - sp * 0.041666668f)));
+    const float big = 1.0f - cad_exp(-sp);
+    return sp < 0.0625f ? poly : big;
+}
 
 // ---- cross-lane primitives (DPP on gfx950; emulated through the fiber exchange in the test build) -----------------
 // Each returns, per lane, the value of `v` in the source lane selected by the pattern, or `old` where the pattern has

@@ -235,6 +235,15 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wx_kernel(cad_proj_args
             wf[mb][ks] = v;
         }
     }
+    // optional epilogue: softplus(. + bias[m]) in fp32 (dt_proj + delta_bias + softplus in one pass); the D lane's channel is
+    // m_wave + 16 mb + jl
+    const bool act_sp = a.act == CAD_ACT_SOFTPLUS_BIAS;  // wave-uniform
+    float brow[C::MB];
+#pragma unroll
+    for (int mb = 0; mb < C::MB; ++mb) {
+        const int m = m_wave + mb * 16 + jl;
+        brow[mb] = (act_sp && a.bias && m < M) ? a.bias[m] : 0.f;
+    }
     gp_wait_dma();
     __syncthreads();
 
@@ -275,6 +284,12 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wx_kernel(cad_proj_args
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                 for (int mb = 0; mb < C::MB; ++mb) d[mb] = cad_mfma_16x16x32_bf16(xf[ks], wf[mb][ks], d[mb]);
+            }
+            if (act_sp) {
+#pragma unroll
+                for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[mb][r] = cad_softplus(d[mb][r] + brow[mb]);
             }
 #pragma unroll
             for (int mb = 0; mb < C::MB; ++mb) {
@@ -453,7 +468,7 @@ static int launch_wxT(const cad_proj_args* a, void* stream) {
 }
 
 extern "C" int cad_proj_wxT(const cad_proj_args* a, void* stream) {
-    CAD_CHECK_ARG(a && a->W && a->X && a->out && a->T > 0 && a->M > 0 && a->K > 0);
+    CAD_CHECK_ARG(a && a->W && a->X && a->out && a->T > 0 && a->M > 0 && a->K > 0 && a->act == 0);
     CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->K && a->ldo >= a->T);
     CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (((uintptr_t)a->W | (uintptr_t)a->X) % 16) == 0);
     CadProfScope prof(8, stream);
@@ -508,7 +523,7 @@ static int launch_wx_thin(const cad_proj_args* a, void* stream) {
 
 extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
     CAD_CHECK_ARG(a && a->W && a->X && a->out && a->T > 0 && a->M > 0 && a->K > 0);
-    if (a->acc == nullptr && cad_proj_wx_thin_supported(a->M, a->K, a->T)) {
+    if (a->acc == nullptr && a->act == 0 && cad_proj_wx_thin_supported(a->M, a->K, a->T)) {
         CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T);
         CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 4) == 0);
         CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X) % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
@@ -521,6 +536,7 @@ extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
         }
     }
     if (!cad_proj_wx_supported(a->K, a->T)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG(a->act == 0 || (a->act == CAD_ACT_SOFTPLUS_BIAS && a->acc == nullptr));
     CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T && (a->acc == nullptr || a->ldacc >= a->T));
     CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 8) == 0 && (a->ldacc % 8) == 0);
     CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X | (uintptr_t)a->out | (uintptr_t)a->acc) % 16) == 0);

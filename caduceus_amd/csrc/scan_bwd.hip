@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
     const float Dv = a.D ? a.D[e] : 0.f;
-    const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
+    const bool is_dt = a.delta_is_dt != 0;  // wave-uniform: delta already holds dt = softplus(delta_raw + bias)
+    const float bias = (a.delta_bias && !is_dt) ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const float keep = act ? 1.f : 0.f;  // padding waves (E % SC_W != 0) contribute nothing
     const int64_t part_stride = (int64_t)N * SB * L;
@@ -254,12 +255,17 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
                 }
             }
+            // softplus: a wave-uniform BRANCH around the whole loop when delta already is dt; per item it is evaluated for
+            // every lane and masked afterwards (a select, not a branch around the transcendental sequence); on the vector
+            // path all items of a lane are in or out of range together
+            if (!is_dt && !(SC_WHATIF & 1024)) {
+#pragma unroll
+                for (int i = 0; i < SC_S; ++i) dt[i] = cad_softplus(dt[i] + bias);
+            }
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
-                // softplus is evaluated for every lane and masked afterwards (a select, not a branch around the
-                // transcendental sequence); on the vector path all items of a lane are in or out of range together
                 const bool ok = VEC ? (p0 < L) : (p0 + i < L);
-                const float sp = (SC_WHATIF & 1024) ? dt[i] + bias : cad_softplus(dt[i] + bias);
+                const float sp = dt[i];
                 const float dti = ok ? sp : 0.f;
                 const float dyi = ok ? dy[i] * keep : 0.f;
                 ddt[i] = 0.f;
@@ -284,10 +290,20 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             float uu[SC_S], dl[SC_S], du[SC_S];
             sc_unpack<T, SC_S>(u_raw, rev, uu);
             sc_unpack<T, SC_S>(d_raw, rev, dl);
+            float sgv[SC_S];
+            if (is_dt) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < SC_S; ++i) sgv[i] = cad_sigmoid_from_softplus(dl[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < SC_S; ++i) {
+                    const float xraw = dl[i] + bias;
+                    sgv[i] = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
-                const float xraw = dl[i] + bias;
-                const float sg = xraw > 20.f ? 1.f : cad_sigmoid(xraw);
+                const float sg = sgv[i];
                 const float dyi = dy2[i >> 1][i & 1];
                 const bool ok = VEC ? (p0 < L) : (p0 + i < L);
                 du[i] = dd[i][0] * gBs[i] + dyi * Dv;
@@ -570,7 +586,8 @@ __global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a)
         const T* g_row = (const T*)a.dout + row_off;
         T* dz_row = (T*)a.gate_fix_dz + row_off;
         const float Dv = a.D ? a.D[e] : 0.f;
-        const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
+        const bool is_dt = a.delta_is_dt != 0;
+        const float bias = (a.delta_bias && !is_dt) ? a.delta_bias[e] : 0.f;
         const int64_t p0 = c * SC_CHUNK + (int64_t)lane * SC_S;
         float y[SC_S];
         f32x2 dd[SC_S];
@@ -579,7 +596,8 @@ __global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a)
             const bool ok = p0 + i < L;
             const int64_t l = ok ? cad_phys(p0 + i, L, rev) : 0;
             const float ui = ok ? to_f32(u_row[l]) : 0.f;
-            const float dti = ok ? cad_softplus(to_f32(d_row[l]) + bias) : 0.f;
+            const float draw = to_f32(d_row[l]) + bias;
+            const float dti = ok ? (is_dt ? draw : cad_softplus(draw)) : 0.f;
             y[i] = Dv * ui;
             dd[i] = f2(dti, dti * ui);
         }

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
     const float Dv = a.D ? a.D[e] : 0.f;
-    const float bias = a.delta_bias ? a.delta_bias[e] : 0.f;
+    const bool is_dt = a.delta_is_dt != 0;  // wave-uniform: delta already holds softplus(delta_raw + bias)
+    const float bias = (a.delta_bias && !is_dt) ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
     constexpr bool PREF = SC_FWD_DMA && VEC && SC_S * sizeof(T) == 32;
@@ -166,11 +167,16 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             sc_load_raw<T, SC_S, VEC>(d_row, p0 + SC_CHUNK, L, rev, d_raw);
         }
 #endif
+        // softplus: a wave-uniform BRANCH around the whole loop when delta already is dt (cad_proj_wx evaluated it); per
+        // item it is evaluated for every lane and masked afterwards (a select instead of a branch around the transcendentals;
+        // on the vector path a lane's items are in or out of range together)
+        if (!is_dt && !(SC_WHATIF & 1024)) {
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) dt[i] = cad_softplus(dt[i] + bias);
+        }
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
-            // evaluated for every lane, masked afterwards: a select instead of a branch around the transcendentals of every
-            // item (on the vector path a lane's items are in or out of range together)
-            const float sp = (SC_WHATIF & 1024) ? dt[i] + bias : cad_softplus(dt[i] + bias);
+            const float sp = dt[i];
             const float dti = (VEC ? (p0 < L) : (p0 + i < L)) ? sp : 0.f;
             y2[i] = f2(Dv * du[i], 0.f);
             dd[i] = f2(dti, dti * du[i]);

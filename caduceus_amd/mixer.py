@@ -106,6 +106,8 @@ def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
 # The two scans of a BiMamba layer share the gate z and the upstream gradient: set 0's backward kernel evaluates the gate
 # gradient of both (cad_scan_bwd_args.out2).  CADUCEUS_AMD_SHARED_GATE=0 keeps one dz per set + an add (A/B switch).
 _SHARED_GATE = os.environ.get("CADUCEUS_AMD_SHARED_GATE", "1") != "0"
+# delta_bias + softplus in the epilogue of the dt_proj kernel (HBM-bound, idle VALU) instead of the scan prologues
+_FUSED_SOFTPLUS = os.environ.get("CADUCEUS_AMD_FUSED_SOFTPLUS", "1") != "0"
 
 
 def prepare_step_cache(pairs, act: torch.dtype) -> None:
@@ -168,6 +170,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             cparams.append((conv_w.float().reshape(E, -1).contiguous(),
                             None if conv_b is None else conv_b.float().contiguous()))
         xcs = _conv_fwd2(x, cparams, split, dirs)
+        fused_sp = []
         for i in range(2):
             conv_w, conv_b, W_x, W_dt, dt_bias, A_log, Dp = ps[7 * i:7 * i + 7]
             N, R = A_log.shape[1], W_dt.shape[1]
@@ -179,9 +182,13 @@ class BiMambaMixerFn(torch.autograd.Function):
             else:
                 dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
             if ops.proj_wx_supported(xc, R, T):  # thin-K MFMA kernel (transposing LDS reads), csrc/gemm.hip
-                delta = ops.proj_wx(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
+                # ... with delta_bias + softplus in its epilogue (fp32): the scans take dt as it is (delta_is_dt)
+                delta = ops.proj_wx(w_dt, dbc[:R].view(R, T),
+                                    softplus_bias=dt_bias.float().contiguous() if _FUSED_SOFTPLUS else None).view(E, SB, Lq)
+                fused_sp.append(_FUSED_SOFTPLUS)
             else:
                 delta = torch.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
+                fused_sp.append(False)
             A = cache["A"][i] if cache else -torch.exp(A_log.float())
             sets.append((xc, delta, A, dbc, Dp.float().contiguous(), dt_bias.float().contiguous(), wf, bf, w_x, w_dt))
         # both parameter sets in one scan launch
@@ -197,6 +204,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             args[i] = L.ScanArgs(L.ptr(xc), L.ptr(delta), L.ptr(A), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bfz),
                                  L.ptr(out), L.ptr(state), SB, Lq, split, E, N, dirs[i][0], dirs[i][1],
                                  L.dtype_code(act))
+            args[i].delta_is_dt = int(fused_sp[i])
             outs.append(out)
             states.append(state)
         L.check(lib.cad_scan_fwd_multi(args, 2, stream), "cad_scan_fwd_multi")
@@ -208,14 +216,14 @@ class BiMambaMixerFn(torch.autograd.Function):
             keep += [xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, states[i], ps[7 * i + 5]]
         ctx.save_for_backward(*keep)
         ctx.meta = (SB, Lq, split, [tuple(None if p is None else (p.dtype, p.shape) for p in ps[7 * i:7 * i + 7])
-                                    for i in range(2)], W_in.dtype, W_out.dtype)
+                                    for i in range(2)], W_in.dtype, W_out.dtype, tuple(fused_sp))
         return out2d
 
     @staticmethod
     def backward(ctx, dout2d):
         lib = L.get_lib()
         x2d, xz, w_in, w_out, ycat, *rest = ctx.saved_tensors
-        SB, Lq, split, pmeta, win_dt, wout_dt = ctx.meta
+        SB, Lq, split, pmeta, win_dt, wout_dt, fused_sp = ctx.meta
         act = x2d.dtype
         T, Dm = x2d.shape
         E = xz.shape[0] // 2
@@ -262,6 +270,7 @@ class BiMambaMixerFn(torch.autograd.Function):
                                     dirs[i][0], dirs[i][1], L.dtype_code(act), npart, None, None,
                                     L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None, L.ptr(fix_list[i]),
                                     L.ptr(fix_cnt[i]), L.ptr(dxz[E:]) if (_SHARED_GATE or i == 0) else L.ptr(dz))
+            args[i].delta_is_dt = int(fused_sp[i])
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
         L.check(lib.cad_scan_bwd_multi(args, 2, stream), "cad_scan_bwd_multi")
         L.check(lib.cad_scan_bwd_gate_fix(args, 2, stream), "cad_scan_bwd_gate_fix")  # no-op unless some z == 0 exactly

@@ -182,7 +182,7 @@ class _ScanMulti(torch.autograd.Function):
     u, delta, A, Bm, Cm, D, delta_bias."""
 
     @staticmethod
-    def forward(ctx, z, split, dirs, *tensors):
+    def forward(ctx, z, split, dirs, delta_is_dt, *tensors):
         nsets = len(tensors) // 7
         lib = L.get_lib()
         z = None if z is None else z.contiguous()
@@ -205,19 +205,20 @@ class _ScanMulti(torch.autograd.Function):
             rl, rh = dirs[i]
             args[i] = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
                                  L.ptr(out), L.ptr(state), SB, Lq, split, E, N, rl, rh, L.dtype_code(u.dtype))
+            args[i].delta_is_dt = int(bool(delta_is_dt))
             sets.append((u, delta, Af, Bm, Cm, Df, bf, state, out))
             outs.append(out)
         L.check(lib.cad_scan_fwd_multi(args, nsets, stream), "cad_scan_fwd_multi")
         flat = [t for s_ in sets for t in s_]
         ctx.save_for_backward(z, *flat)
         ctx.meta = (split, dirs, nsets, [(t[2].dtype, t[5].dtype, t[6].dtype) for t in
-                                         [tensors[7 * i:7 * i + 7] for i in range(nsets)]])
+                                         [tensors[7 * i:7 * i + 7] for i in range(nsets)]], bool(delta_is_dt))
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
         z, *flat = ctx.saved_tensors
-        split, dirs, nsets, pdt = ctx.meta
+        split, dirs, nsets, pdt, delta_is_dt = ctx.meta
         lib = L.get_lib()
         args = (L.ScanBwdArgs * nsets)()
         keep, res = [], []
@@ -239,6 +240,7 @@ class _ScanMulti(torch.autograd.Function):
                                     L.ptr(dA), L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
                                     rl, rh, L.dtype_code(u.dtype), npart, None, None, None, L.ptr(fix_list),
                                     L.ptr(fix_cnt), L.ptr(dz))
+            args[i].delta_is_dt = int(delta_is_dt)
             keep.append((dout, dBC, fix_list, fix_cnt))
             res.append([du, ddelta, dA, dBC, dD, dbias, dz])
         L.check(lib.cad_scan_bwd_multi(args, nsets, stream), "cad_scan_bwd_multi")
@@ -260,15 +262,17 @@ class _ScanMulti(torch.autograd.Function):
             grads += [du, ddelta, dA.to(Adt), dB, dC, dD.to(Ddt), dbias.to(bdt)]
             if dz is not None:
                 dz_tot = dz if dz_tot is None else dz_tot.add_(dz)
-        return (dz_tot, None, None, *grads)
+        return (dz_tot, None, None, None, *grads)
 
 
-def selective_scan_multi(sets, z, split: int, dirs):
+def selective_scan_multi(sets, z, split: int, dirs, delta_is_dt: bool = False):
     """sets: list of (u, delta, A, Bm, Cm, D, delta_bias) with u, delta: (E, SB, L); A: (E, N) (= -exp(A_log));
     Bm, Cm: (N, SB, L); D, delta_bias: (E).  z: shared gate (E, SB, L) or None.  dirs: [(rev_lo, rev_hi)] per set.
-    mamba_ssm `selective_scan_fn(..., delta_softplus=True)` for each set, each row in its own direction."""
+    mamba_ssm `selective_scan_fn(..., delta_softplus=True)` for each set, each row in its own direction.
+    delta_is_dt: `delta` already holds dt = softplus(delta_raw + delta_bias) (proj_wx(..., softplus_bias=)); its gradient is
+    still the one w.r.t. delta_raw, and delta_bias still receives its gradient."""
     flat = [t for s_ in sets for t in s_]
-    return _ScanMulti.apply(z, int(split), tuple((int(a), int(b)) for a, b in dirs), *flat)
+    return _ScanMulti.apply(z, int(split), tuple((int(a), int(b)) for a, b in dirs), bool(delta_is_dt), *flat)
 
 
 def selective_scan(u, delta, A, Bm, Cm, D, z, delta_bias, split: int, rev_lo: int, rev_hi: int) -> torch.Tensor:
@@ -479,17 +483,20 @@ def proj_wx_supported(t: torch.Tensor, K: int, T: int, M: Optional[int] = None) 
 
 
 def proj_wx(W: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None,
-            acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+            acc: Optional[torch.Tensor] = None, softplus_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out (M, T) = W (M, K) @ X (K, T) [+ acc (M, T)], all channel-major bf16, thin K (cad_proj_wx).  `acc` may be `out`
-    itself (in-place accumulate)."""
+    itself (in-place accumulate).  softplus_bias (M) fp32: out = softplus(W @ X + bias) evaluated in fp32 (thin K only)."""
     M, K = W.shape
     T = X.shape[1]
     if X.shape[0] != K or W.stride(1) != 1 or X.stride(1) != 1:
         raise ValueError("proj_wx: W (M, K) and X (K, T) with unit inner stride")
     if out is None:
         out = torch.empty((M, T), dtype=torch.bfloat16, device=X.device)
-    stream = L.stream_and_check(W, X, out, acc, contiguous=False)
+    stream = L.stream_and_check(W, X, out, acc, softplus_bias, contiguous=False)
+    if softplus_bias is not None and (softplus_bias.dtype != torch.float32 or softplus_bias.numel() != M or
+                                      not softplus_bias.is_contiguous()):
+        raise ValueError("proj_wx: softplus_bias must be a contiguous fp32 vector of M elements")
     a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0), L.ptr(acc),
-                   0 if acc is None else acc.stride(0))
+                   0 if acc is None else acc.stride(0), L.ptr(softplus_bias), 0 if softplus_bias is None else 1)
     L.check(L.get_lib().cad_proj_wx(C.byref(a), stream), "cad_proj_wx")
     return out

@@ -197,6 +197,8 @@ typedef struct {
     const float* h0;
     float* hT;
     float* sum_dt;
+    int delta_is_dt;   /* 1: `delta` already holds dt = softplus(delta_raw + delta_bias) (written by cad_proj_wx with
+                        * act = CAD_ACT_SOFTPLUS_BIAS); delta_bias is ignored */
 } cad_scan_args;
 int cad_scan_fwd(const cad_scan_args* a, void* stream);
 /* Same, for nsets (1 or 2) independent parameter sets of identical shape in ONE launch -- the mamba_fwd and mamba_rev
@@ -251,6 +253,8 @@ typedef struct {
     int64_t* gate_fix_list;
     int* gate_fix_count;
     void* gate_fix_dz;
+    int delta_is_dt;   /* as in cad_scan_args; ddelta / ddelta_bias are still the gradients w.r.t. delta_raw / the bias:
+                        * d(dt) * sigmoid(delta_raw + bias) = d(dt) * (1 - exp(-dt)) */
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
@@ -317,7 +321,12 @@ typedef struct {
     int64_t ldw, ldx, ldo;
     const void* acc;   /* cad_proj_wx only: optional (M, T) addend, may alias out; NULL = none */
     int64_t ldacc;
+    const float* bias; /* cad_proj_wx, K <= 64, no addend: per-row bias (M) of the activation below, or NULL */
+    int act;           /* 0 = none; CAD_ACT_SOFTPLUS_BIAS: out = softplus(W . X + bias) evaluated in fp32 -- dt_proj + delta_bias +
+                        * softplus of mamba_inner_fn / selective_scan_fn(delta_softplus=True) in one pass (the scans then take
+                        * delta_is_dt = 1) */
 } cad_proj_args;
+#define CAD_ACT_SOFTPLUS_BIAS 1
 int cad_proj_wxT(const cad_proj_args* a, void* stream);
 int cad_proj_supported(int K);
 /* cad_proj_wx:  out (M, T) = W (M, K) . X (K, T) [+ acc],  all channel-major, thin K (cad_proj_wx_supported: K <= 64,

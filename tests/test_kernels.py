@@ -414,3 +414,31 @@ def test_embed_large_vocabulary_backward(backend, n_strands):
     (torch.stack(ref) * up).sum().backward()
     assert torch.equal(out.detach().cpu(), torch.stack(ref).detach())
     torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(5, 2, 75, 4, 1, 0, 1), (8, 2, 1100, 16, 1, 1, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_takes_dt_computed_by_the_projection(backend, case, dtype):
+    """delta_is_dt: the scans take dt = softplus(delta_raw + bias) as produced by cad_proj_wx's epilogue.  Same output, and
+    the gradients are still those w.r.t. delta_raw and the bias (d dt * sigmoid(raw) = d dt * (1 - exp(-dt)))."""
+    name, dev = backend
+    E, SB, L, N, split, rl, rh = case
+    t = _scan_inputs(E, SB, L, N, 23, dev, dtype)
+    order = ("u", "delta", "A", "B", "C", "D", "z", "bias")
+    act = {"u", "delta", "B", "C", "z"}
+    raw = [leaf(t[k], dev, dtype if k in act else torch.float32) for k in order]
+    out_raw = ops.selective_scan(*raw, split, rl, rh)
+    (out_raw.float() * t["w"].to(dev)).sum().backward()
+    # dt from the RAW (dtype-rounded) delta the first run saw, evaluated in fp32: in fp32 both runs see the same dt bit for bit
+    dt = torch.nn.functional.softplus(raw[1].detach().float() + raw[7].detach()[:, None, None], threshold=20.0).to(dtype)
+    fused = [leaf(t[k], dev, dtype if k in act else torch.float32) for k in order]
+    fused[1] = dt.clone().requires_grad_(True)
+    u, d, A, B, C, D, z, b = fused
+    out = ops.selective_scan_multi([(u, d, A, B, C, D, b)], z, split, [(rl, rh)], delta_is_dt=True)[0]
+    (out.float() * t["w"].to(dev)).sum().backward()
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(out.float(), out_raw.float(), **tol)
+    for k, a, r in zip(order, fused, raw):
+        scale = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.float(), r.grad.float(), rtol=tol["rtol"], atol=tol["atol"] * scale,
+                                   msg=lambda m, k=k: f"d{k}: {m}")

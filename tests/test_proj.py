@@ -84,3 +84,16 @@ def test_proj_wx_thin_m_deep_k(backend, M, K, T):
     Xp = X.view(K, T // 8, 8)[:, perm].reshape(K, T).contiguous()
     outp = ops.proj_wx(W.to(dev), Xp.to(dev))
     assert torch.equal(outp.view(M, T // 8, 8).cpu(), out.view(M, T // 8, 8)[:, perm].cpu())
+
+
+@pytest.mark.parametrize("M,K,T", [(512, 16, 256), (70, 24, 136)])
+def test_proj_wx_softplus_bias_epilogue(backend, M, K, T):
+    """dt_proj + delta_bias + softplus in one pass (fp32 evaluation, one rounding to bf16)."""
+    name, dev = backend
+    W, X = _bf(M, K, seed=31), _bf(K, T, seed=32)
+    bias = torch.randn(M, generator=torch.Generator().manual_seed(33)) - 2.0
+    out = ops.proj_wx(W.to(dev), X.to(dev), softplus_bias=bias.to(dev))
+    ref = torch.nn.functional.softplus(W.float() @ X.float() + bias[:, None], threshold=20.0)
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=1.6e-2, atol=1e-6)
+    with pytest.raises(Exception):
+        ops.proj_wx(W.to(dev), X.to(dev), acc=out, softplus_bias=bias.to(dev))
