@@ -153,6 +153,14 @@ __device__ __forceinline__ float cad_softplus(float x) {
     const float sp = (d == 0.0f) ? e : lp;
     return (x > 20.0f) ? x : sp;
 }
+// softplus for results that are rounded to bf16 anyway: max(x, 0) + log(1 + exp(-|x|)) -- two transcendentals instead of
+// three; below t = exp(-|x|) ~ 1e-4 the plain log(1 + t) keeps only 3-4 digits of a term that is < 1e-4 in absolute value
+// (and is replaced by t itself below 2^-12), far inside bf16's 8 bits
+__device__ __forceinline__ float cad_softplus_lowp(float x) {
+    const float t = cad_exp(-fabsf(x));
+    const float l = t < 0.000244140625f ? t : cad_log(1.0f + t);
+    return fmaxf(x, 0.0f) + l;
+}
 __device__ __forceinline__ float cad_sigmoid(float x) { return cad_rcp(1.0f + cad_exp(-x)); }
 // sigmoid(x) recovered from sp = softplus(x):  1 - exp(-sp)  (series below 1/16: no cancellation for tiny sp)
 __device__ __forceinline__ float cad_sigmoid_from_softplus(float sp) {

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wx_kernel(cad_proj_args
 #pragma unroll
                 for (int mb = 0; mb < C::MB; ++mb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d[mb][r] = cad_softplus(d[mb][r] + brow[mb]);
+                    for (int r = 0; r < 4; ++r) d[mb][r] = cad_softplus_lowp(d[mb][r] + brow[mb]);
             }
 #pragma unroll
             for (int mb = 0; mb < C::MB; ++mb) {
