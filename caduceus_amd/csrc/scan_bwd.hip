@@ -365,11 +365,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 acc_h = av[i] * acc_h + hs[i];
             }
             SC_TIME(3);  // exp + serial scan
-            f32x2 PA = acc_a, PH = acc_h;
-            if (!(SC_WHATIF & 512)) wave_scan_fwd(PA, PH);
-            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
-            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
-            const f32x2 h0 = ea * hin + eh;  // state entering this lane's segment
+            f32x2 PH = acc_h;
+            if (!(SC_WHATIF & 512)) wave_scan_fwd_carry(acc_a, PH, hin, lane);  // PH: the true state leaving each lane
+            const f32x2 h0 = f2(dpp_wave_shr1(hin[0], PH[0]), dpp_wave_shr1(hin[1], PH[1]));  // state entering this lane's segment
             // the true h_i (forward chain) and 2. the reverse scan of G (backward chain), interleaved: two independent
             // serial v_pk_fma chains, each step of one fills the wait state the other needs between dependent packed ops
             SC_TIME(4);  // forward wave scan

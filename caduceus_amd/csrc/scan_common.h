@@ -225,6 +225,36 @@ __device__ __forceinline__ void wave_scan_fwd(f32x2& A, f32x2& H) {
 #endif
 }
 
+// The forward scan with the state entering lane 0 (`hin`, wave-uniform) folded into lane 0's map before the scan: on return H of
+// lane j is the TRUE state leaving lane j; the map products are dead afterwards (no exclusive shift of A, no `A * hin + H` per
+// lane, no A update in the last step).
+__device__ __forceinline__ void wave_scan_fwd_carry(f32x2 A, f32x2& H, f32x2 hin, int lane) {
+#ifdef CAD_EMU
+    if (lane == 0) H = A * hin + H;
+    wave_scan_fwd(A, H);
+#else
+    // every lane of the wave is active here (wave-uniform trip counts): exec is restored to all ones
+    asm volatile(
+        "s_mov_b32 exec_lo, 1\n\t"
+        "s_mov_b32 exec_hi, 0\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(H)
+        : "v"(A), "s"(hin));
+    float h0 = H[0], h1 = H[1], a0 = A[0], a1 = A[1];
+    asm("s_nop 1\n\t"
+        SC_KS_ASM("row_shr:1 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_shr:4 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_shr:8 row_mask:0xf bank_mask:0xf")
+        SC_KS_ASM("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_fmac_f32_dpp %0, %0, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        : "+v"(h0), "+v"(h1), "+v"(a0), "+v"(a1));
+    H = f2(h0, h1);
+#endif
+}
+
 // Inclusive scan in REVERSE lane order (lane 63 first): (A, G) of lane j is the composition of lanes 63..j.
 // Row-local steps use DPP row_shl; the two cross-row steps have no DPP broadcast in this direction and go through
 // v_readlane + masked updates.

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             if (!(SC_WHATIF & 512)) wave_scan_fwd(PA, PH);
             const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
             const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
-            // (iii) carry in / out
+            // (iii) carry in / out  (folding the carry into lane 0 before the scan, as the backward does, measured +0.8 % here)
             const f32x2 hin = readlane2(carry, np);
             const f32x2 h0 = ea * hin + eh;
             // state entering lane 32 = state at logical position base + 512: the backward's half-chunk start
