@@ -85,6 +85,8 @@ def _wgrad_cm_cm(a_cm: torch.Tensor, b_cm: torch.Tensor) -> torch.Tensor:
     """a (M, T) @ b (N, T)^T with both operands channel-major (T contiguous) -> (M, N) fp32."""
     M, T = a_cm.shape
     n = _kchunks(T)
+    if b_cm.shape[0] <= 16 and n >= 64 and T % 16 == 0:
+        n = 16  # thin products (dW_dt): fewer, deeper chunks (tools/wgrad_sweep.py: 48 vs 55 us at T = 262144)
     if n == 1:
         return torch.mm(a_cm, b_cm.t()).float()
     Kc = T // n
