@@ -21,6 +21,7 @@
 #endif
 
 #define CAD_WAVE 64
+#define CAD_MAX_DEVICES 64   // per-device launch-attribute caches (GP_BIG_LDS / SC_BIG_LDS)
 
 // dynamic LDS (16-byte aligned base; keep ALL of a kernel's LDS in this one region - guide G17)
 #ifdef CAD_EMU
@@ -370,6 +371,13 @@ __device__ __forceinline__ bool cad_wave_any(bool p) {
 __device__ __forceinline__ void cad_sched_fence() {
 #ifndef CAD_EMU
     asm volatile("" ::: "memory");
+#endif
+}
+
+// scheduling fence: nothing is moved across this point by the instruction scheduler (device build)
+__device__ __forceinline__ void cad_sched_group_fence() {
+#ifndef CAD_EMU
+    __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 

@@ -435,18 +435,22 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
 
 }  // namespace
 
-// more than 64 KB of dynamic LDS has to be requested per kernel (once)
+// more than 64 KB of dynamic LDS has to be requested per kernel: the largest size asked for so far is remembered per
+// call site (= per kernel instantiation) AND per device, so a later launch with a larger K (or on another GPU of the same
+// process) raises the attribute again
 #if defined(CAD_EMU)
 #define GP_BIG_LDS(kern, bytes) (void)0
 #else
 #define GP_BIG_LDS(kern, bytes)                                                                                      \
     do {                                                                                                             \
-        static bool done = false;                                                                                    \
-        if ((bytes) > 65536 && !done) {                                                                              \
+        static size_t cur[CAD_MAX_DEVICES] = {0};                                                                    \
+        int dev_ = 0;                                                                                                \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= CAD_MAX_DEVICES) return CAD_ERR_LAUNCH;         \
+        if ((size_t)(bytes) > 65536 && (size_t)(bytes) > cur[dev_]) {                                                \
             if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != \
                 hipSuccess)                                                                                          \
                 return CAD_ERR_LAUNCH;                                                                               \
-            done = true;                                                                                             \
+            cur[dev_] = (size_t)(bytes);                                                                             \
         }                                                                                                            \
     } while (0)
 #endif

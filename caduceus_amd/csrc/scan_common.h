@@ -358,7 +358,7 @@ __device__ __forceinline__ void wave_scan_rev_carry(f32x2 A, f32x2& G, f32x2 gin
 
 // ---- per-lane item vectors -------------------------------------------------------------------------------------------
 template <typename T, int S>
-struct __attribute__((aligned(16))) ScVec {
+struct __attribute__((aligned(sizeof(T) * S >= 16 ? 16 : sizeof(T) * S))) ScVec {
     T v[S];
 };
 
@@ -751,18 +751,20 @@ __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float*
     }
 }
 
-// more than 64 KB of dynamic LDS has to be requested per kernel (once)
+// more than 64 KB of dynamic LDS has to be requested per kernel; remembered per call site and per device (see gemm.hip)
 #if defined(CAD_EMU)
 #define SC_BIG_LDS(kern, bytes) (void)0
 #else
-#define SC_BIG_LDS(kern, bytes)                                                                                  \
+#define SC_BIG_LDS(kern, bytes)                                                                                      \
     do {                                                                                                             \
-        static bool done = false;                                                                                    \
-        if ((bytes) > 65536 && !done) {                                                                              \
+        static size_t cur[CAD_MAX_DEVICES] = {0};                                                                    \
+        int dev_ = 0;                                                                                                \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= CAD_MAX_DEVICES) return CAD_ERR_LAUNCH;         \
+        if ((size_t)(bytes) > 65536 && (size_t)(bytes) > cur[dev_]) {                                                \
             if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != \
                 hipSuccess)                                                                                          \
-                return CAD_ERR_LAUNCH;                                                                                 \
-            done = true;                                                                                             \
+                return CAD_ERR_LAUNCH;                                                                               \
+            cur[dev_] = (size_t)(bytes);                                                                             \
         }                                                                                                            \
     } while (0)
 #endif

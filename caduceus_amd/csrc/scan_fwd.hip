@@ -28,6 +28,10 @@ struct ScanFwdSets {
 #ifndef SC_RING_FWD
 #define SC_RING_FWD (SC_FWD_DMA ? 4 : 8)   // the prefetch slots take 64 KB of the LDS the deeper ring used (-1.7 %)
 #endif
+#ifndef SC_FWD_CPRE
+#define SC_FWD_CPRE 0                      // 1: the C tile of a pair is read from LDS BEFORE the wave scan (32 VGPRs) instead of batch by
+                                           // batch in the output phase (measured neutral: 1.37-1.40 ms either way, round 3)
+#endif
 #define PRE_SLOT (SC_W * 64 * 16)          // bytes per 16-byte plane (all waves)
 #define PRE_BYTES (8 * PRE_SLOT)           // u0 u1 d0 d1 | z0 z1 (even chunks) | z0 z1 (odd chunks)
 
@@ -218,6 +222,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
                 hh[i] = acc_h;
             }
             SC_TIME(2);  // staging issue + exp + serial scan (B tile reads)
+            f32x4 cpre[SC_S / 2];
+            if constexpr (SC_FWD_CPRE != 0) {
+#pragma unroll
+                for (int i = 0; i < SC_S; i += 2) cpre[i / 2] = *(const f32x4*)(tC + 2 * i);
+                cad_sched_fence();
+            }
             // (ii) inclusive scan of the affine maps across lanes (DPP)
             f32x2 PA = acc_a, PH = acc_h;
             if (!(SC_WHATIF & 512)) wave_scan_fwd(PA, PH);
@@ -241,7 +251,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
                 const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
-                const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]} : *(const f32x4*)(tC + 2 * i);
+                const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]}
+                                 : (SC_FWD_CPRE != 0 ? cpre[i / 2] : *(const f32x4*)(tC + 2 * i));
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
             }

@@ -261,6 +261,74 @@ def gen_vep(rec):
     print("vep ok:", idx, rc_idx)
 
 
+def gen_vep_dump(rec):
+    """The reference's whole `dump_embeddings` (vep_embeddings.py:275-404: DistributedSampler + DataLoader batching, the four
+    forwards / the RCPS strand split :363-376, the nested `extract_embeddings` window means :277-307, the per-rank .pt file)
+    executed as it stands, on the reference's own `Caduceus` backbone (through oracle/ref_harness), one RCPS and one
+    non-RCPS model, world size 1 over gloo.  Only numbers are kept: parameters, token ids, the dumped tensors."""
+    import tempfile
+    import datasets
+    import torch.distributed as dist
+    from caduceus.configuration_caduceus import CaduceusConfig
+    from caduceus.modeling_caduceus import Caduceus
+    vep = importlib.import_module("vep_embeddings")
+    comp = torch.tensor([COMP.get(j, j) for j in range(16)])
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1)
+    for i, (name, over) in enumerate([("ps", dict()), ("ph", dict(rcps=False))]):
+        gen = torch.Generator().manual_seed(400 + i)
+        torch.manual_seed(400 + i)
+        cfg_dict = make_cfg(**over)
+        cfg = CaduceusConfig(**json.loads(json.dumps(cfg_dict), object_hook=_intkeys))
+        backbone = Caduceus(cfg)
+        randomize_(backbone, gen)
+        backbone.eval()
+        L = 40
+        splits = {}
+        for split, n in (("train", 5), ("test", 4)):  # batch size 2, drop_last: the fifth training variant is dropped
+            ref = torch.randint(7, 11, (n, L), generator=gen)
+            alt = ref.clone()
+            pos = torch.tensor([L // 2, 3, L - 2, L // 2, 17][:n])
+            alt[torch.arange(n), pos] = 7 + (alt[torch.arange(n), pos] - 7 + 1) % 4
+            cols = {"ref_input_ids": ref, "alt_input_ids": alt, "ref_rc_input_ids": comp[ref.flip(-1)],
+                    "alt_rc_input_ids": comp[alt.flip(-1)]}
+            vi = [vep.find_variant_idx({k: v[j].tolist() for k, v in cols.items()}) for j in range(n)]
+            cols = {k: v.tolist() for k, v in cols.items()}
+            cols["variant_idx"] = [r["variant_idx"] for r in vi]
+            cols["rc_variant_idx"] = [r["rc_variant_idx"] for r in vi]
+            cols["chromosome"] = list(range(1, n + 1))
+            cols["labels"] = [j % 2 for j in range(n)]
+            cols["distance_to_nearest_tss"] = [100 * j + 7 for j in range(n)]
+            cols["tissue"] = [["liver", "lung", "brain"][j % 3] for j in range(n)]
+            splits[split] = datasets.Dataset.from_dict(cols)
+        ds = datasets.DatasetDict(splits)
+        p = f"vepdump/{name}/"
+        with tempfile.TemporaryDirectory() as tmp:
+            args = types.SimpleNamespace(downstream_save_dir=tmp, name="run", embed_dump_batch_size=2, num_workers=0,
+                                         rcps=bool(cfg.rcps), model_name_or_path="caduceus-ref", bp_per_token=128)
+            model = lambda ids: backbone(ids).last_hidden_state  # noqa: E731  (DNAEmbeddingModel.forward, :56-60)
+            vep.dump_embeddings(args, ds, model, torch.device("cpu"))
+            for split in ("train", "test"):
+                got = torch.load(os.path.join(tmp, "run", f"{split}_embeds_0.pt"))
+                for k, v in got.items():
+                    rec[p + f"{split}/{k}"] = _np(v)
+        rec[p + "cfg"] = np.frombuffer(json.dumps(dict(cfg=cfg_dict, batch_size=2, bp_per_token=128)).encode(), dtype=np.uint8)
+        for k, v in backbone.state_dict().items():
+            rec[p + "sd/" + k] = _np(v)
+        for split in ("train", "test"):
+            for k in ("ref_input_ids", "alt_input_ids", "ref_rc_input_ids", "alt_rc_input_ids", "variant_idx", "chromosome",
+                      "labels", "distance_to_nearest_tss"):
+                rec[p + f"{split}/in/{k}"] = np.array(ds[split][k], dtype=np.int64)
+        print(f"vep dump {name}: train {tuple(rec[p + 'train/concat_avg_ws'].shape)} test {tuple(rec[p + 'test/concat_avg_ws'].shape)}")
+    # rank sharding of the same pipeline for world sizes > 1: the reference's sampler class itself
+    from torch.utils.data import DistributedSampler
+    for n, world in ((11, 2), (9, 4), (8, 3)):
+        for r in range(world):
+            smp = DistributedSampler(list(range(n)), num_replicas=world, rank=r, shuffle=False, drop_last=True)
+            rec[f"vepdump/shard/{n}_{world}_{r}"] = np.array(list(iter(smp)), dtype=np.int64)
+    dist.destroy_process_group()
+
+
 def main():
     _install_placeholders()
     rec = {"meta": np.frombuffer(json.dumps(dict(torch=torch.__version__, generator="oracle/gen_golden_downstream.py")
@@ -268,6 +336,7 @@ def main():
     gen_seqcls(rec)
     gen_embedding_and_decoder(rec)
     gen_vep(rec)
+    gen_vep_dump(rec)
     np.savez_compressed(OUT, **rec)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(rec), "arrays")
 

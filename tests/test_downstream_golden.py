@@ -130,3 +130,42 @@ def test_find_variant_idx_matches_reference():
     assert vep.find_variant_idx(ref, alt).tolist() == Z["vep/variant_idx"].tolist()
     assert vep.find_variant_idx(ref_rc, alt_rc, rc=True).tolist() == Z["vep/rc_variant_idx"].tolist()
     assert vep.WINDOW_SIZE_BP == int(Z["vep/window_size_bp"])
+
+
+@pytest.mark.parametrize("name", ["ps", "ph"])
+def test_vep_dump_matches_reference_dump_embeddings(backend, name):
+    """`vep.dump_embeddings` (window means, RCPS strand split / the two extra RC forwards, batching with drop_last) against
+    the tensors the REFERENCE's own `dump_embeddings` wrote for the same backbone weights and token ids
+    (/root/reference/vep_embeddings.py:275-404, executed by oracle/gen_golden_downstream.py::gen_vep_dump)."""
+    from caduceus_amd import Caduceus
+    _, dev = backend
+    g = _group(f"vepdump/{name}/")
+    meta = _meta(g)
+    cfg = CaduceusConfig(**meta["cfg"])
+    model = Caduceus(cfg)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}, strict=True)
+    model = model.to(dev).eval()
+    backbone = lambda ids: model(ids, return_dict=False)  # noqa: E731
+    for split in ("train", "test"):
+        data = {k[len(split) + 4:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith(f"{split}/in/")}
+        data["tissue_embed"] = torch.arange(data["labels"].shape[0])  # label encoding is data preparation: passed through
+        out = vep.dump_embeddings(backbone, data, rcps=bool(cfg.rcps), batch_size=meta["batch_size"],
+                                  bp_per_token=meta["bp_per_token"], autocast_dtype=None)
+        n = g[f"{split}/concat_avg_ws"].shape[0]
+        assert n == (data["labels"].shape[0] // meta["batch_size"]) * meta["batch_size"]  # drop_last
+        for k in ("concat_avg_ws", "rc_concat_avg_ws"):
+            torch.testing.assert_close(out[k], torch.from_numpy(g[f"{split}/{k}"]), **FP32)
+        for k in ("chromosome", "labels", "distance_to_nearest_tss"):
+            assert out[k].tolist() == g[f"{split}/{k}"].tolist()
+        assert out["tissue_embed"].tolist() == list(range(n))
+
+
+def test_vep_rank_sharding_matches_distributed_sampler():
+    """`vep.shard_batches` against index lists produced by torch's DistributedSampler(shuffle=False, drop_last=True), the
+    sampler the reference builds (vep_embeddings.py:333-338), followed by DataLoader(drop_last=True) batching."""
+    for n, world in ((11, 2), (9, 4), (8, 3)):
+        for r in range(world):
+            want = Z[f"vepdump/shard/{n}_{world}_{r}"].tolist()
+            for bs in (1, 2, 3):
+                batches = [want[i:i + bs] for i in range(0, len(want) - bs + 1, bs)]
+                assert vep.shard_batches(n, r, world, bs) == batches

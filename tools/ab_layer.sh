@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU box: same-box A/B of one production mixer layer (tools/layer_bench.py) over variant libraries.
+# usage: tools/ab_layer.sh <rounds> <variant> [<variant> ...]   ("default" = caduceus_amd/libcaduceus_hip.so)
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+rounds=$1; shift
+: > gpurun_out/ab_layer.log
+for r in $(seq 1 $rounds); do
+  for v in "$@"; do
+    if [ "$v" = default ]; then unset CADUCEUS_AMD_LIB; else export CADUCEUS_AMD_LIB=caduceus_amd/libcaduceus_hip_$v.so; fi
+    timeout 180 python tools/layer_bench.py 2>/dev/null | grep layer_ms >> gpurun_out/ab_layer.log
+  done
+done
+unset CADUCEUS_AMD_LIB
+cat gpurun_out/ab_layer.log
