@@ -55,6 +55,12 @@ def active() -> bool:
 
 
 def _all_gather(t: torch.Tensor, group) -> List[torch.Tensor]:
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # bring-up path (several ranks sharing one GPU, where RCCL refuses duplicate devices): gloo has no device all_gather,
+        # the (tiny) maps / halos travel through host memory
+        host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(host, t.detach().cpu().contiguous(), group=group)
+        return [h.to(t.device) for h in host]
     out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, t.contiguous(), group=group)
     return out

@@ -15,6 +15,8 @@ sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+REL1_BOUND = 0.12   # configs[1], 16 layers bf16 (calibrated below)
+REL2_BOUND = 0.05   # configs[2] layer shape, 1 layer bf16
 
 
 @pytest.fixture(autouse=True)
@@ -93,15 +95,18 @@ def test_config1_ph_d256_n16_L1024_bf16_vs_oracle():
     assert rel < 3e-2, rel
     assert abs(float(out.loss) - float(ref["loss"])) < 0.05 * max(1.0, float(ref["loss"]))
     named = dict(model.named_parameters())
-    worst = 1.0
+    errs = {}
     for k, p in named.items():
         want = sd[k].grad
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
         if float(want.norm()) > 1e-6:
-            cos = float(F.cosine_similarity(p.grad.float().cpu().flatten(), want.flatten(), dim=0))
-            worst = min(worst, cos)
-            assert cos > 0.97, (k, cos)
-    assert worst > 0.97
+            errs[k] = float((p.grad.float().cpu() - want).norm() / want.norm())
+    worst = max(errs, key=errs.get)
+    print("config1 gradient relative-norm errors: worst", worst, errs[worst], "median", sorted(errs.values())[len(errs) // 2])
+    # per-parameter relative error norms of the bf16 16-layer backward against the fp32 oracle (measured on the MI355X in round 3:
+    # median REL1_MEDIAN, worst REL1_WORST); cos > 0.97 of earlier rounds corresponds to 0.25 here
+    for k, e in errs.items():
+        assert e < REL1_BOUND, (k, e)
 
 
 def test_config2_full_model_16_layers_L131072():
@@ -137,6 +142,36 @@ def test_config2_full_model_16_layers_L131072():
               "caduceus.backbone.embeddings.word_embeddings.embedding.weight"):
         cos = float(F.cosine_similarity(ga[k].flatten().float(), gb[k].flatten().float(), dim=0))
         assert cos > 0.999, (k, cos)
+
+
+def test_config2_one_layer_L131072_every_gradient_vs_oracle():
+    """One layer of the headline model at its full length (PS d_model=256, seqlen=131072, bf16 autocast) held to the fp32
+    oracle (oracle_model + the C/OpenMP scan of cad_oracle.c on the host cores): logits, loss and EVERY parameter gradient by
+    relative error norm -- the layer shape of configs[2], through in_proj / conv / x_proj / dt_proj epilogue / both scans /
+    partial-slot reduction / out_proj and the RCPS embedding and head."""
+    from bench import make_config, synthetic_batch
+    from caduceus_amd import CaduceusForMaskedLM
+    torch.manual_seed(77)
+    model = CaduceusForMaskedLM(make_config(256, 1)).to(DEV).train()
+    ids, labels = synthetic_batch(torch.Generator().manual_seed(9), 1, 131072, DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(ids, labels=labels)
+    out.loss.backward()
+    ref, sd = _oracle_step(model, _oracle_cfg(1, True), ids, labels)
+    rel = float((out.logits.float().cpu() - ref["logits"]).norm() / ref["logits"].norm())
+    assert rel < 2e-2, rel
+    assert abs(float(out.loss) - float(ref["loss"])) < 2e-2 * max(1.0, float(ref["loss"]))
+    errs = {}
+    for k, p in model.named_parameters():
+        want = sd[k].grad
+        assert want is not None and p.grad is not None and torch.isfinite(p.grad).all(), k
+        if float(want.norm()) > 1e-9:
+            errs[k] = float((p.grad.float().cpu() - want).norm() / want.norm())
+    worst = max(errs, key=errs.get)
+    print("config2 one-layer gradient relative-norm errors:", {k: round(v, 5) for k, v in errs.items()})
+    assert len(errs) >= 15
+    for k, e in errs.items():
+        assert e < REL2_BOUND, (k, e)
 
 
 def test_config3_bucketed_allreduce_through_rccl():

@@ -442,3 +442,46 @@ def test_scan_takes_dt_computed_by_the_projection(backend, case, dtype):
         scale = max(1.0, float(r.grad.abs().max()))
         torch.testing.assert_close(a.grad.float(), r.grad.float(), rtol=tol["rtol"], atol=tol["atol"] * scale,
                                    msg=lambda m, k=k: f"d{k}: {m}")
+
+
+@pytest.mark.parametrize("case", [(8, 2, 1100, 16, 1, 1, 0), (16, 1, 2100, 16, 1, 0, 0)])
+def test_fused_softplus_rounding_point_against_oracle(backend, case):
+    """bf16: the production path rounds dt = softplus(raw + bias) to bf16 (dt_proj epilogue, delta_is_dt) where mamba-ssm rounds
+    the RAW delta and evaluates softplus / sigmoid in fp32 inside the scan.  Both HIP paths are held
+    to the fp32 oracle on the same bf16-rounded raw delta: output and every gradient -- d(delta), d(bias) in particular -- of the
+    fused path stay inside the bf16 tolerance class AND within 1.5x the un-fused path's error norm (+ a floor), so moving the
+    rounding point does not cost accuracy."""
+    name, dev = backend
+    E, SB, L, N, split, rl, rh = case
+    dtype = torch.bfloat16
+    t = _scan_inputs(E, SB, L, N, 29, dev, dtype)
+    t["delta"] = (0.5 * t["delta"] - 1.0).to(dtype).float()  # raw pre-activations around the dt range of a trained model
+    order = ("u", "delta", "A", "B", "C", "D", "z", "bias")
+    act = {"u", "delta", "B", "C", "z"}
+    ref_ins = [leaf(t[k], "cpu") for k in order]
+    u, d, A, B, C, D, z, b = ref_ins
+    ref = _rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, A, B_, C_, D, z_, b), [u, d, B, C, z],
+                       split, rl, rh)
+    (ref * t["w"]).sum().backward()
+    raw = [leaf(t[k], dev, dtype if k in act else torch.float32) for k in order]
+    out_raw = ops.selective_scan(*raw, split, rl, rh)
+    (out_raw.float() * t["w"].to(dev)).sum().backward()
+    fused = [leaf(t[k], dev, dtype if k in act else torch.float32) for k in order]
+    dt = torch.nn.functional.softplus(fused[1].detach().float() + fused[7].detach()[:, None, None], threshold=20.0).to(dtype)
+    fused[1] = dt.clone().requires_grad_(True)
+    fu, fd, fA, fB, fC, fD, fz, fb = fused
+    out = ops.selective_scan_multi([(fu, fd, fA, fB, fC, fD, fb)], fz, split, [(rl, rh)], delta_is_dt=True)[0]
+    (out.float() * t["w"].to(dev)).sum().backward()
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), **BF16)
+
+    def rel(x, want):
+        return float((x.float().cpu() - want).norm() / want.norm().clamp_min(1e-12))
+
+    e_out_f, e_out_r = rel(out, ref.detach()), rel(out_raw, ref.detach())
+    assert e_out_f < 1.5 * e_out_r + 2e-3, (e_out_f, e_out_r)
+    for k, a, r0, r in zip(order, fused, raw, ref_ins):
+        scale = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.float().cpu(), r.grad, rtol=BF16["rtol"], atol=BF16["atol"] * scale,
+                                   msg=lambda m, k=k: f"d{k} (fused): {m}")
+        ef, er = rel(a.grad, r.grad), rel(r0.grad, r.grad)
+        assert ef < 1.5 * er + 4e-3, (k, ef, er)

@@ -20,15 +20,18 @@ def _free_port():
     return p
 
 
-def _setup_model(name):
-    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
-    from build_emu import build_emu
+def _setup_model(name, device="cpu"):
     from caduceus_amd import CaduceusConfig, CaduceusForMaskedLM, _lib
-    _lib.use_library_for_testing(build_emu())
+    if device == "cpu":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        from build_emu import build_emu
+        _lib.use_library_for_testing(build_emu())
+    else:
+        _lib.use_library_for_testing(None)  # the real gfx950 library
     cfg, sd, rec = load_golden_model(name)
     model = CaduceusForMaskedLM(CaduceusConfig(**cfg, pad_token_id=4))
     model.load_state_dict(sd)
-    return model.train(), rec
+    return model.to(device).train(), rec
 
 
 def _long_batch(rec, L):
@@ -39,15 +42,16 @@ def _long_batch(rec, L):
     return ids, labels
 
 
-def _worker(rank, world, port, out_dir, name, L):
+def _worker(rank, world, port, out_dir, name, L, device="cpu", backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from caduceus_amd import seqpar
     from caduceus_amd.dp import BucketedGradReducer
-    model, rec = _setup_model(name)
+    model, rec = _setup_model(name, device)
     reducer = BucketedGradReducer(model.parameters(), average=False)  # partial sums over each rank's tokens
     ids, labels = _long_batch(rec, L)
+    ids, labels = ids.to(device), labels.to(device)
     seg = slice(rank * L // world, (rank + 1) * L // world)
     reducer.zero_grad()
     with seqpar.sequence_parallel():
@@ -57,7 +61,8 @@ def _worker(rank, world, port, out_dir, name, L):
     reducer.finish()
     total = loss.detach().clone()
     dist.all_reduce(total)
-    torch.save({"logits": logits.detach(), "loss": total, "grads": {n: p.grad.clone() for n, p in model.named_parameters()}},
+    torch.save({"logits": logits.detach().cpu(), "loss": total.cpu(),
+                "grads": {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -80,3 +85,61 @@ def test_sequence_parallel_matches_single_process(tmp_path, name, L):
         scale = max(1.0, float(p.grad.abs().max()))
         torch.testing.assert_close(parts[0]["grads"][n], p.grad, rtol=2e-3, atol=2e-4 * scale, msg=lambda m, n=n: f"{n}: {m}")
         assert torch.equal(parts[0]["grads"][n], parts[1]["grads"][n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,L", [("ps_fused", 4224), ("ph_fused", 2112)])
+def test_sequence_parallel_two_processes_on_the_gpu(tmp_path, name, L):
+    """f-4 on the device: two processes share cuda:0, each runs its half of every sequence through the real gfx950 kernels
+    (state carries h0 / hT / sum_dt, dhT / dh0 of the scan C-ABI; conv halos), the segment maps and halos are exchanged between
+    the ranks (gloo -- RCCL refuses two ranks on one device; the RCCL binding itself is covered by the 1-rank test below), and
+    logits, loss and every parameter gradient equal the single-process run on the same GPU.  Multi-chunk segments with tails."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), name, L, "cuda:0", "gloo"), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    model, rec = _setup_model(name, "cuda:0")
+    ids, labels = _long_batch(rec, L)
+    out = model(ids.to("cuda:0"), labels=labels.to("cuda:0"))
+    out.loss.backward()
+    logits = torch.cat([p["logits"] for p in parts], 1)
+    torch.testing.assert_close(logits, out.logits.detach().cpu(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(parts[0]["loss"], out.loss.detach().cpu(), rtol=1e-5, atol=1e-6)
+    for n, p in model.named_parameters():
+        g = p.grad.detach().cpu()
+        scale = max(1.0, float(g.abs().max()))
+        torch.testing.assert_close(parts[0]["grads"][n], g, rtol=2e-3, atol=2e-4 * scale, msg=lambda m, n=n: f"{n}: {m}")
+
+
+@pytest.mark.gpu
+def test_sequence_parallel_one_rank_through_rccl():
+    """The sequence-parallel path with its collectives on RCCL ("nccl" backend, device tensors): a 1-rank group on cuda:0 runs both
+    scan passes, the all-gathers of the segment maps / halos and the loss all-reduce through RCCL; with one segment the result
+    must equal the plain path."""
+    from caduceus_amd import seqpar
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        model, rec = _setup_model("ps_fused", "cuda:0")
+        ids, labels = _long_batch(rec, 2112)
+        ids, labels = ids.to("cuda:0"), labels.to("cuda:0")
+        out = model(ids, labels=labels)
+        out.loss.backward()
+        plain = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        with seqpar.sequence_parallel():
+            logits = model(ids).logits
+            loss = seqpar.masked_lm_loss(logits, labels, ignore_index=4)
+        loss.backward()
+        torch.testing.assert_close(logits, out.logits.detach(), rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(loss.detach(), out.loss.detach(), rtol=1e-5, atol=1e-6)
+        for n, p in model.named_parameters():
+            scale = max(1.0, float(plain[n].abs().max()))
+            torch.testing.assert_close(p.grad, plain[n], rtol=2e-3, atol=2e-4 * scale, msg=lambda m, n=n: f"{n}: {m}")
+    finally:
+        if created:
+            dist.destroy_process_group()
