@@ -124,11 +124,18 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="sequences per OPTIMIZER step over all GPUs (reference: 8, configs/experiment/hg38/hg38.yaml:17 "
                          "accumulate_grad_batches = global / (gpus * batch)); 0 = weak scaling, one micro-batch per step")
+    ap.add_argument("--fp8-proj", action="store_true",
+                    help="configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores -- per-token activation scales, per-row weight "
+                         "scales, fp32 accumulation (csrc/gemm_fp8.hip); everything else stays bf16")
     ap.add_argument("--model", default="ps", choices=["ps", "ph"],
                     help="ps: RCPS (configs[2..4], the headline); ph: no RCPS wrapper, RC augmentation is a data-side flip "
                          "(configs[1], run with --seqlen 1024 --batch 128)")
     args = ap.parse_args()
 
+    if args.fp8_proj:
+        if args.dtype != "bf16":
+            raise SystemExit("--fp8-proj runs inside the bf16 path")
+        os.environ["CADUCEUS_AMD_FP8_PROJ"] = "1"
     import torch.distributed as dist
     from caduceus_amd import CaduceusForMaskedLM, _lib
     from caduceus_amd.dp import BucketedGradReducer
@@ -217,29 +224,41 @@ def main():
         inv_tokens = (4 if args.model == "ps" else 2) * args.batch * args.seqlen
         alg = {"scan_fwd": (4 * E + 2 * N) * s * inv_tokens, "scan_bwd": (7 * E + 4 * N) * s * inv_tokens}
         kinds = {}
+        # one scan OPERATION per layer and micro-step; with the L-split (Caduceus-Ph at batch 1) an operation is two launches
+        # (map / carry pass + full pass): the algorithmic bytes are divided by the time of BOTH
+        n_ops = args.n_layer * args.steps * accum
         for k in ("scan_fwd", "scan_bwd"):
             ms, n = prof[k]
             if n:
-                kinds[k] = {"launches": n, "avg_ms": ms / n, "achieved_GBps": alg[k] / (ms / n * 1e-3) / 1e9,
-                            "algorithmic_bytes_per_launch": alg[k], "total_ms": ms}
+                kinds[k] = {"launches": n, "launches_per_op": n / n_ops, "avg_ms": ms / n_ops,
+                            "achieved_GBps": alg[k] / (ms / n_ops * 1e-3) / 1e9, "algorithmic_bytes_per_launch": alg[k],
+                            "total_ms": ms}
         dom = max(kinds, key=lambda k: kinds[k]["total_ms"]) if kinds else None
         roofline = None
         # HBM traffic of one scan launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with
         # rocprofv3 --pmc at exactly this launch shape); null for any other shape
-        traffic = None
+        # ... and only when the profile was taken on THIS build of the kernels (cad_version() carries a hash of the sources)
+        traffic, traffic_note = None, "no counter profile for this launch shape"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_scan_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_scan_pmc.json")))
             sh = pmc["shape"]
             if dom and (sh["E"], sh["L"], sh["N"], sh["dtype"]) == (E, args.seqlen, N, args.dtype) and \
                     sh["rows"] == (2 if args.model == "ps" else 1) * args.batch:
-                traffic = pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"]
+                if pmc.get("lib_version") == _lib.version():
+                    traffic = pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"]
+                    traffic_note = ("HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
+                                    "profiles/r03_scan_pmc.json taken on this build (" + _lib.version() + ")")
+                else:
+                    traffic_note = (f"profiles/r03_scan_pmc.json was taken on another build ({pmc.get('lib_version')}); this "
+                                    f"library is {_lib.version()}: not quoted")
         except (OSError, KeyError, ValueError):
             traffic = None
         if dom:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": kinds[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": kinds[dom]["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_note": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_scan_pmc.json)",
+                        "traffic_note": traffic_note,
                         "avg_launch_ms": kinds[dom]["avg_ms"], "launches": kinds[dom]["launches"],
+                        "launches_per_layer_op": kinds[dom]["launches_per_op"],
                         "algorithmic_bytes_per_launch": kinds[dom]["algorithmic_bytes_per_launch"],
                         "all": {k: {"avg_ms": v["avg_ms"], "achieved_GBps": v["achieved_GBps"],
                                     "share_of_step": v["total_ms"] / (elapsed * 1e3)} for k, v in kinds.items()},
@@ -270,6 +289,25 @@ def main():
                     "GBps": by / ms / 1e6, "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS,
                     "note": "K = d_model: HBM-bound (arithmetic intensity ~200 flop/B), not MFMA-bound; MFMA-busy counters "
                             "in profiles/r02_proj_pmc_summary.txt"}
+            if args.fp8_proj and _ops.fp8_proj_supported(xx, args.d_model):
+                wq, sw = _ops.quant_weight_fp8(ww)
+                xq, sx = _ops.quant_rows_fp8(xx)
+                run8 = lambda: _ops.proj_wxT_fp8(wq, sw, xq, sx)  # noqa: E731
+                runq = lambda: _ops.quant_rows_fp8(xx)  # noqa: E731
+                res8 = {}
+                for nm, fn in (("in_proj_fp8", run8), ("quant_rows_fp8", runq)):
+                    for _ in range(3):
+                        fn()
+                    e0.record()
+                    for _ in range(10):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res8[nm + "_ms"] = e0.elapsed_time(e1) / 10
+                by8 = Tt * args.d_model + 2 * E * args.d_model + Tt * 2 * E * 2  # e4m3 operands, bf16 output
+                proj["fp8"] = {**res8, "TFLOPs": fl / res8["in_proj_fp8_ms"] / 1e9, "mfma_peak_TFLOPs": 5000.0,
+                               "GBps": by8 / res8["in_proj_fp8_ms"] / 1e6,
+                               "kernel": "cad_proj_wxT_fp8 (v_mfma_f32_16x16x32_fp8_fp8, per-token / per-row scales)"}
             del xx, ww
         except Exception as ex:  # evidence only
             proj = {"error": repr(ex)}
@@ -286,7 +324,8 @@ def main():
             "metric": "DNA tokens/sec (whole node), hg38-style MLM pre-train step", "value": tokens / elapsed,
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype + (" (in_proj: fp8 e4m3 MFMA, fp32 accumulate)" if args.fp8_proj else ""),
+            "data": "synthetic",
             "config": {"workload": f"Caduceus-{args.model.upper() if args.model == 'ps' else 'Ph'} d_model={args.d_model} "
                                    f"n_layer={args.n_layer} seqlen={args.seqlen} rcps={'true' if args.model == 'ps' else 'false'} "
                                    f"MLM fwd+bwd+allreduce+AdamW, {args.batch} seq/GPU"

@@ -20,6 +20,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash(defines=()) -> str:
+    """Identifies the kernel sources (+ tuning defines) a library was built from: compiled into cad_version(), recorded next to
+    every committed counter profile, compared by bench.py before it quotes such a profile."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "caduceus_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    for d in sorted(defines):
+        h.update(d.encode())
+    return h.hexdigest()[:12]
+
+
 def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = LIB, extra_flags=()) -> str:
     """Cross-compiles every kernel for gfx950 (works without a GPU).  Objects are built in parallel.
     `defines` / `out` build tuning variants (e.g. ("SC_S=8",)) next to the default library for A/B measurements."""
@@ -30,7 +43,7 @@ def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = 
     objdir = os.path.join(HERE, "build", os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
-    flags += [f"-D{d}" for d in defines] + list(extra_flags)
+    flags += [f"-D{d}" for d in defines] + list(extra_flags) + [f'-DCAD_SRC_HASH="{source_hash(defines)}"']
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

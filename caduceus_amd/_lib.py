@@ -62,7 +62,7 @@ class ScanArgs(C.Structure):
     _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
                 ("delta_bias", _p), ("out", _p), ("chunk_state", _p), ("SB", _i64), ("L", _i64), ("split", _i64),
                 ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i), ("h0", _p), ("hT", _p),
-                ("sum_dt", _p), ("delta_is_dt", _i)]
+                ("sum_dt", _p), ("delta_is_dt", _i), ("map_only", _i)]
 
 
 class ScanBwdArgs(C.Structure):
@@ -71,14 +71,7 @@ class ScanBwdArgs(C.Structure):
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
                 ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p), ("gate_fix_list", _p), ("gate_fix_count", _p),
-                ("gate_fix_dz", _p), ("delta_is_dt", _i)]
-
-
-class ScanTmArgs(C.Structure):
-    _fields_ = [("u", _p), ("delta", _p), ("z", _p), ("A", _p), ("BC", _p), ("D", _p), ("delta_bias", _p), ("out", _p),
-                ("state", _p), ("scratch", _p), ("SB", _i64), ("L", _i64), ("split", _i64), ("ld_u", _i64),
-                ("ld_delta", _i64), ("ld_z", _i64), ("ld_bc", _i64), ("ld_out", _i64), ("E", _i), ("N", _i),
-                ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
+                ("gate_fix_dz", _p), ("delta_is_dt", _i), ("carry_only", _i)]
 
 
 class MlmArgs(C.Structure):
@@ -90,6 +83,15 @@ class MlmArgs(C.Structure):
 class ProjArgs(C.Structure):
     _fields_ = [("W", _p), ("X", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
                 ("ldo", _i64), ("acc", _p), ("ldacc", _i64), ("bias", _p), ("act", _i)]
+
+
+class QuantFp8Args(C.Structure):
+    _fields_ = [("x", _p), ("q", _p), ("scale", _p), ("T", _i64), ("K", _i), ("ldx", _i64), ("ldq", _i64), ("dtype", _i)]
+
+
+class ProjFp8Args(C.Structure):
+    _fields_ = [("Wq", _p), ("Xq", _p), ("sw", _p), ("sx", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i),
+                ("ldw", _i64), ("ldx", _i64), ("ldo", _i64)]
 
 
 class LmHeadArgs(C.Structure):
@@ -121,16 +123,14 @@ SYMBOLS = {
     "cad_scan_bwd_partials": (_i, [_i]),
     "cad_scan_bwd_gate_fix": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_scan_gate_fix_entries": (_i64, [_i, _i64, _i64]),
-    "cad_scan_tm_fwd": (_i, [C.POINTER(ScanTmArgs), _p]),
-    "cad_scan_tm_fwd_multi": (_i, [C.POINTER(ScanTmArgs), _i, _p]),
-    "cad_scan_tm_block_len": (_i64, []),
-    "cad_scan_tm_state_floats": (_i64, [_i, _i64, _i64, _i]),
-    "cad_scan_tm_scratch_floats": (_i64, [_i, _i64, _i64, _i]),
     "cad_proj_wxT": (_i, [C.POINTER(ProjArgs), _p]),
     "cad_proj_supported": (_i, [_i]),
     "cad_proj_wx": (_i, [C.POINTER(ProjArgs), _p]),
     "cad_proj_wx_supported": (_i, [_i, _i64]),
     "cad_proj_wx_thin_supported": (_i, [_i, _i, _i64]),
+    "cad_quant_rows_fp8": (_i, [C.POINTER(QuantFp8Args), _p]),
+    "cad_proj_wxT_fp8": (_i, [C.POINTER(ProjFp8Args), _p]),
+    "cad_proj_fp8_supported": (_i, [_i]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_lm_head_partials": (_i64, [_i64]),
     "cad_tokenize_mlm": (_i, [C.POINTER(MlmArgs), _p]),
@@ -231,6 +231,11 @@ def stream_and_check(*tensors, contiguous=True):
     if dev_build:
         return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
     return None
+
+
+def version() -> str:
+    """cad_version() of the loaded library, e.g. "caduceus_amd 0.1.0 (hip gfx950) src 3f2a9c0d1b7e" (hash of the kernel sources)."""
+    return get_lib().cad_version().decode()
 
 
 def prof_enable(on: bool):

@@ -8,7 +8,11 @@ extern "C" const char* cad_version(void) {
 #ifdef CAD_EMU
     return "caduceus_amd 0.1.0 (host emulator build - tests only)";
 #else
+#ifdef CAD_SRC_HASH
+    return "caduceus_amd 0.1.0 (hip gfx950) src " CAD_SRC_HASH;
+#else
     return "caduceus_amd 0.1.0 (hip gfx950)";
+#endif
 #endif
 }
 

@@ -63,18 +63,6 @@ struct ScanBwdSets {
 #endif
 #define PRE_SLOT (SC_W * 64 * 16)       // bytes per vector slot (all waves)
 #define PRE_BYTES (SC_NDMA * PRE_SLOT)
-// Latency-hiding variants, measured on one MI355X in round 3 (profiles/r03_ab_scan_latency_variants.txt) and OFF by default:
-// the kernels run against the chip's power limit (2.04 GHz under this kernel, 2.46 GHz under a streaming one), so hiding a
-// stall buys clock, not time, and the extra live registers / LDS bursts behind the barrier cost 2-7 %.
-#ifndef SC_BWD_ROT
-#define SC_BWD_ROT 0                    // 1: rotated pair loop -- the NEXT pair's B/C tile is read from LDS right behind the
-                                        // flush's slab reads; 2: ... and the next pair's exponentials run under those reads
-                                        // (3.82 -> 3.90 / 4.01 ms per two-set launch)
-#endif
-#ifndef SC_BWD_DAREG
-#define SC_BWD_DAREG 0                  // 1 (d_state <= 16): dA accumulates per LANE in 16 registers indexed by the pair
-                                        // (s_set_gpr_idx), eight wave sums per kernel instead of one per pair-step (3.82 -> 3.80)
-#endif
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
 #endif
@@ -84,18 +72,10 @@ static_assert(SC_W == 4 || SC_W == 8, "staging needs >= 256 threads; the flush m
 
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1])); }
 
-// 16 per-lane accumulators addressed with a wave-uniform runtime subscript: as a vector type they stay in VGPRs (relative
-// addressing through s_set_gpr_idx_on), as an array they would go to scratch
-struct DaRegs {
-#ifdef CAD_EMU
-    float v[16];
-#else
-    typedef float vec16 __attribute__((ext_vector_type(16)));
-    vec16 v;
-#endif
-};
-
-template <typename T, bool VEC>
+// CO = carry-only instantiation (cad_scan_bwd_args.carry_only, pass 1 of an L-split backward): the reverse recurrence of the
+// state gradient alone -- exp, C * dy, one chain per item and state, the reverse wave scan -- and dh0 as its only output.  A
+// separate instantiation, so the full kernel carries none of its branches (measured: +5 % when they were run-time branches).
+template <typename T, bool VEC, bool CO>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][wave][dB,dC][ACC_TILE] contributions
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
@@ -129,7 +109,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const T* d_row = (const T*)a.delta + row_off;
     const T* z_row = a.z ? (const T*)a.z + row_off : nullptr;
     const T* g_row = (const T*)a.dout + row_off;
-    T* dz_row = a.dz ? (T*)a.dz + row_off : nullptr;
+    T* dz_row = (a.dz && !CO) ? (T*)a.dz + row_off : nullptr;
     const T* o_row = (a.out && dz_row) ? (const T*)a.out + row_off : nullptr;      // only the gate gradient needs it
     const T* o2_row = (a.out2 && dz_row) ? (const T*)a.out2 + row_off : nullptr;  // the other scan under the same gate
     T* du_row = (T*)a.du + row_off;
@@ -193,17 +173,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
     }
     f32x2 hin_next = f2(0.f);
-    if (lane < NP) {
+    if (!CO && lane < NP) {
         const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + nchunks - 1) * NP + lane) * 2;
         hin_next = f2(stp[0], stp[1]);
     }
     f32x2 dAacc = f2(0.f);   // lane np: dA of pair np
-    // d_state <= 16 (wave-uniform): every lane keeps its own partial sums of dA for all pairs in 16 registers addressed by
-    // the pair index (the compiler emits s_set_gpr_idx for the wave-uniform subscript); summed over the wave once, at the end
-    const bool da_reg = SC_BWD_DAREG && NP <= 8;
-    DaRegs dAl;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) dAl.v[q] = 0.f;
     float dDacc = 0.f, dbacc = 0.f;
     int tix = 0;
 
@@ -247,7 +221,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 // out = y * z * sigmoid(z)  =>  y * sigmoid(z) = out / z ;  dz = dout * y * sigmoid(z) * (1 + z (1 - sigmoid(z)))
                 float zz[SC_S], oo[SC_S], dzv[SC_S];
                 sc_unpack<T, SC_S>(z_raw, rev, zz);
-                if (a.gate_fix_list) {
+                if (!CO && a.gate_fix_list) {
                     // out / z cannot recover y where the gate is exactly 0 (out == 0 there): remember the chunk, the
                     // fix-up launch (cad_scan_bwd_gate_fix) recomputes y for it and adds dout * y / 2 to dz
                     int z0 = 0;  // (bitwise, not short-circuit: no branch per item)
@@ -308,7 +282,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         // running states of all pairs at this chunk's start (saved by the forward): lane np holds pair np; the next
         // (earlier) chunk's states are fetched now and land while this chunk computes
         const f32x2 hin_reg = hin_next;
-        if (lane < NP && c > 0) {
+        if (!CO && lane < NP && c > 0) {
             const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c - 1) * NP + lane) * 2;
             hin_next = f2(stp[0], stp[1]);
         }
@@ -345,31 +319,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
         };
         SC_TIME(1);  // chunk prologue: unpack, gate, softplus
-        // B and C of a pair are each needed twice (recompute / gradient step, reverse scan / gradient step): they are read
-        // from the LDS tile once per pair -- for the first pair of a chunk at its top, for the others right behind the barrier
-        // of the pair before (SC_BWD_ROT), where the read latency hides under the flush
-        f32x2 Cv[SC_S], Bw[SC_S];
-        auto read_tile = [&](int b) {
-            const float* tB = smem + b * 2 * TILE + lane * ROW;
-            const float* tC = tB + TILE;
-#pragma unroll
-            for (int i = 0; i < SC_S; ++i) {
-                if (SC_WHATIF & 64)
-                    Bw[i] = f2(__builtin_bit_cast(float, lane + i)), Cv[i] = f2(__builtin_bit_cast(float, lane - i));
-                else
-                    Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
-            }
-        };
-        // a_i = exp2(dt_i A) of the lane's items and their product, for one pair: depends on nothing but the chunk's dt and A,
-        // so with SC_BWD_ROT >= 2 the NEXT pair's exponentials are evaluated between the flush's slab reads and its MFMAs
-        f32x2 av[SC_S], acc_a;
-        auto calc_av = [&](int pq) {
-            const f32x2 A2q = readlane2(Areg, pq) * f2(CAD_LOG2E);
-            acc_a = exp2_2(f2(sum_dt) * A2q);  // product of the lane's a_i
-#pragma unroll
-            for (int i = 0; i < SC_S; ++i)
-                av[i] = (SC_WHATIF & 128) ? splat_lo(dd[i]) * A2q : exp2_2(splat_lo(dd[i]) * A2q);
-        };
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);
@@ -389,19 +338,43 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if constexpr (PREF) {
                 if (dma_now) prefetch_vectors(p0 - SC_CHUNK);
             }
+            const float* tB = smem + buf * 2 * TILE + lane * ROW;
+            const float* tC = tB + TILE;
             float* aB = acc + (SC_SLAB_BUFS == 2 ? buf : 0) * ACC_BUF + wave * 2 * ACC_TILE + lane * 2;  // (i, s) at aB[i * ACC_ISTR + s]: 8-byte stride
             float* aC = aB + ACC_TILE;
             const int n0 = 2 * np;
             const f32x2 Av = readlane2(Areg, np);
+            const f32x2 A2 = Av * f2(CAD_LOG2E);
             const f32x2 hin = readlane2(hin_reg, np);
-            if (!SC_BWD_ROT || np == 0) read_tile(buf);
-            SC_TIME(2);  // staging issue + B/C tile reads
-            // 1. forward recompute: serial totals, wave scan, then the true h_i
-            f32x2 hs[SC_S];
-            f32x2 acc_h = f2(0.f);
-            if (SC_BWD_ROT < 2 || np == 0) calc_av(np);
+            // B and C of this pair are each needed twice (recompute / gradient step, reverse scan / gradient step): read
+            // them from the LDS tile once, up front
+            f32x2 Cv[SC_S], Bw[SC_S];
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
+                if (SC_WHATIF & 64)
+                    Bw[i] = f2(__builtin_bit_cast(float, lane + i)), Cv[i] = f2(__builtin_bit_cast(float, lane - i));
+                else
+                    Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
+            }
+            SC_TIME(2);  // staging issue + B/C tile reads
+            if constexpr (CO) {
+                // reverse recurrence of the state gradient alone: G_i = a_i (C_i dy_i + G_{i+1}), lane-local, then across the wave
+                const f32x2 acc_a = exp2_2(f2(sum_dt) * A2);
+                f32x2 RGc = f2(0.f);
+#pragma unroll
+                for (int r = SC_S - 1; r >= 0; --r) RGc = exp2_2(splat_lo(dd[r]) * A2) * (Cv[r] * SC_DY(r) + RGc);
+                const f32x2 ginc = readlane2(carryG, np);
+                wave_scan_rev_carry(acc_a, RGc, ginc, lane);
+                const f32x2 newcc = readlane2(RGc, 0);
+                if (lane == np) carryG = newcc;
+            } else {
+            // 1. forward recompute: serial totals, wave scan, then the true h_i
+            f32x2 av[SC_S], hs[SC_S];
+            f32x2 acc_h = f2(0.f);
+            const f32x2 acc_a = exp2_2(f2(sum_dt) * A2);  // product of the lane's a_i
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                av[i] = (SC_WHATIF & 128) ? splat_lo(dd[i]) * A2 : exp2_2(splat_lo(dd[i]) * A2);
                 hs[i] = splat_hi(dd[i]) * Bw[i];  // b_i
                 acc_h = av[i] * acc_h + hs[i];
             }
@@ -468,18 +441,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }
             }
             SC_TIME(7);  // gradient loop + slab writes
-            if (da_reg) {
-                const int q = 2 * cad_uniform(np);
-                dAl.v[q] += dAp[0];
-                dAl.v[q + 1] += dAp[1];
-            } else {
-                dAp = wave_sum2_dpp(dAp);
-                if (lane == np) dAacc = dAacc + dAp * f2(keep);
-            }
-            if constexpr (!PREF) {
+            dAp = wave_sum2_dpp(dAp);
+            if (lane == np) dAacc = dAacc + dAp * f2(keep);
+            if constexpr (!PREF && !CO) {
                 // (register prefetch: the next chunk's vectors overwrite u_raw / d_raw behind this pair's barrier)
                 if (np == NP - 1) chunk_epilogue();
             }
+            }  // !CO
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
             if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
             SC_TIME(9);  // staging store (waits for the tile loads)
@@ -499,6 +467,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             // sum the SC_W regions and flush: thread t owns one tensor (dB / dC), one state of the pair and FT
             // consecutive positions, stored 4 at a time (8/16-byte stores).  With two slab buffers the next pair writes
             // the other buffer, so one barrier per pair suffices.
+            if constexpr (CO) continue;  // no slab, no flush
             if constexpr (PACKED) {
                 if (!(SC_WHATIF & 32)) {
                 // wave w sums tensor (w >> 2), lanes 16 (w & 3) .. + 15 over the 8 channels on the matrix core
@@ -506,25 +475,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const int g = lane >> 4, jl = lane & 15;
                 const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + (jb * 16 + jl) * 4 + g * (2 * PK_TILE);
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-                u32x4 fb0[2], fb1[2];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    fb0[hf] = *(const u32x4*)(src + hf * (8 * PK_TILE));
-                    fb1[hf] = *(const u32x4*)(src + hf * (8 * PK_TILE) + PK_Q);
+                    const u32x4 b0 = *(const u32x4*)(src + hf * (8 * PK_TILE));
+                    const u32x4 b1 = *(const u32x4*)(src + hf * (8 * PK_TILE) + PK_Q);
+                    d0 = cad_mfma_16x16x32_bf16(selA, b0, d0);
+                    d1 = cad_mfma_16x16x32_bf16(selA, b1, d1);
                 }
-                if (SC_BWD_ROT >= 2) {  // the next pair's exponentials run while the slab reads are in flight
-                    cad_sched_group_fence();
-                    if (np + 1 < NP) calc_av(np + 1);
-                    cad_sched_group_fence();
-                }
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    d0 = cad_mfma_16x16x32_bf16(selA, fb0[hf], d0);
-                    d1 = cad_mfma_16x16x32_bf16(selA, fb1[hf], d1);
-                }
-                // the next pair's tile (staged during this pair-step, published by the barrier): issued BEHIND the slab reads
-                // (the LDS queue is in order), its latency runs under the MFMAs and the stores below
-                if (SC_BWD_ROT && np + 1 < NP) read_tile(buf ^ 1);
                 // lanes 0..31: g = state of the pair; d0 = items 0..3, d1 = items 4..7 of lane (jb, jl); pieces of lanes with
                 // bit 3 set were stored with their item pairs exchanged (bank swizzle of the slab writes)
                 if (SC_BWD_SLAB_SWZ && (jl & 8)) {
@@ -596,27 +553,17 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     }
                 }
             }
-            if (SC_BWD_ROT && !(PACKED && !(SC_WHATIF & 32)) && np + 1 < NP) {
-                read_tile(buf ^ 1);
-                if (SC_BWD_ROT >= 2) calc_av(np + 1);
-            }
             if (SC_SLAB_BUFS == 1) __syncthreads();  // the slab is rewritten by the next pair
             SC_TIME(11);  // next chunk's loads issued + flush
         }
-        if constexpr (PREF) chunk_epilogue();
+        if constexpr (PREF && !CO) chunk_epilogue();
     }
     if (a.dh0 && act && lane < NP) {  // gradient w.r.t. the state entering the row
         float* gp = a.dh0 + ((int64_t)e * SB + sb) * N + 2 * lane;
         gp[0] = carryG[0];
         if (2 * lane + 1 < N) gp[1] = carryG[1];
     }
-    if (da_reg) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x2 t = wave_sum2_dpp(f2(dAl.v[2 * q], dAl.v[2 * q + 1]));
-            if (lane == q) dAacc = t * f2(keep);
-        }
-    }
+    if constexpr (CO) return;  // nothing else is an output of a carry-only pass
     // per-channel parameter gradients (E x N, E: a few device-scope atomics per wave, once per kernel)
     if (act && lane < NP) {
         const int n0 = 2 * lane;
@@ -762,14 +709,19 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     ScanBwdSets ks;
     for (int i = 0; i < nsets; ++i) {
         const cad_scan_bwd_args* a = &sets[i];
-        CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && a->dout && a->chunk_state);
-        CAD_CHECK_ARG(a->du && a->ddelta && a->dA && a->dB && a->dC);
+        CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && a->dout);
+        if (a->carry_only) {
+            CAD_CHECK_ARG(a->dh0 != nullptr);
+        } else {
+            CAD_CHECK_ARG(a->chunk_state && a->du && a->ddelta && a->dA && a->dB && a->dC);
+        }
+        CAD_CHECK_ARG(a->carry_only == sets[0].carry_only);
         CAD_CHECK_ARG(a->z != nullptr || a->dz == nullptr);               // dz needs the gate; dz == NULL: not wanted here
         CAD_CHECK_ARG(a->dz == nullptr || a->out != nullptr);
         CAD_CHECK_ARG(a->out2 == nullptr || a->dz != nullptr);
         CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
         CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
-        CAD_CHECK_ARG(a->n_partials == cad_scan_bwd_partials(a->E));
+        CAD_CHECK_ARG(a->carry_only || a->n_partials == cad_scan_bwd_partials(a->E));
         CAD_CHECK_ARG(a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L && a->N == sets[0].N &&
                       a->dtype == sets[0].dtype);
         ks.s[i] = *a;
@@ -788,10 +740,15 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) * sizeof(float) +
                          (pref ? PRE_BYTES : 0);
-#define SC_BWD_LAUNCH(T, V)                                                      \
-    do {                                                                         \
-        SC_BIG_LDS((scan_bwd_kernel<T, V>), shmem);                              \
-        CAD_LAUNCH((scan_bwd_kernel<T, V>), grid, block, shmem, stream, ks);     \
+#define SC_BWD_LAUNCH(T, V)                                                                  \
+    do {                                                                                     \
+        if (a->carry_only) {                                                                 \
+            SC_BIG_LDS((scan_bwd_kernel<T, V, true>), shmem);                                \
+            CAD_LAUNCH((scan_bwd_kernel<T, V, true>), grid, block, shmem, stream, ks);       \
+        } else {                                                                             \
+            SC_BIG_LDS((scan_bwd_kernel<T, V, false>), shmem);                               \
+            CAD_LAUNCH((scan_bwd_kernel<T, V, false>), grid, block, shmem, stream, ks);      \
+        }                                                                                    \
     } while (0)
     if (a->dtype == CAD_F32) {
         if (vec)

@@ -28,14 +28,12 @@ struct ScanFwdSets {
 #ifndef SC_RING_FWD
 #define SC_RING_FWD (SC_FWD_DMA ? 4 : 8)   // the prefetch slots take 64 KB of the LDS the deeper ring used (-1.7 %)
 #endif
-#ifndef SC_FWD_CPRE
-#define SC_FWD_CPRE 0                      // 1: the C tile of a pair is read from LDS BEFORE the wave scan (32 VGPRs) instead of batch by
-                                           // batch in the output phase (measured neutral: 1.37-1.40 ms either way, round 3)
-#endif
 #define PRE_SLOT (SC_W * 64 * 16)          // bytes per 16-byte plane (all waves)
 #define PRE_BYTES (8 * PRE_SLOT)           // u0 u1 d0 d1 | z0 z1 (even chunks) | z0 z1 (odd chunks)
 
-template <typename T, bool VEC>
+// MO = map-only instantiation (cad_scan_args.map_only, pass 1 of an L-split scan): recurrence and wave scan only -- hT and
+// sum_dt are the outputs; no C tile reads, no output phase, no gate, no stores of `out` / chunk states.
+template <typename T, bool VEC, bool MO>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [SC_RING_FWD slots][B,C][SC_TILE]
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
@@ -56,7 +54,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const int64_t row_off = ((int64_t)e * SB + sb) * L;
     const T* u_row = (const T*)a.u + row_off;
     const T* d_row = (const T*)a.delta + row_off;
-    const T* z_row = a.z ? (const T*)a.z + row_off : nullptr;
+    const T* z_row = (a.z && !MO) ? (const T*)a.z + row_off : nullptr;
     T* o_row = (T*)a.out + row_off;
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
@@ -190,7 +188,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             for (int i = 0; i < SC_S; ++i) sdt += dd[i][0];
         }
         // running state at this chunk's start (first slot of the chunk); a mid-chunk state (second slot) is written per pair
-        float* st_base = a.chunk_state ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + SLOTS * c) * NP * 2 : nullptr;
+        float* st_base = (a.chunk_state && !MO) ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + SLOTS * c) * NP * 2 : nullptr;
         if (st_base && act && lane < NP) {
             st_base[lane * 2] = carry[0];
             st_base[lane * 2 + 1] = carry[1];
@@ -222,12 +220,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
                 hh[i] = acc_h;
             }
             SC_TIME(2);  // staging issue + exp + serial scan (B tile reads)
-            f32x4 cpre[SC_S / 2];
-            if constexpr (SC_FWD_CPRE != 0) {
-#pragma unroll
-                for (int i = 0; i < SC_S; i += 2) cpre[i / 2] = *(const f32x4*)(tC + 2 * i);
-                cad_sched_fence();
-            }
             // (ii) inclusive scan of the affine maps across lanes (DPP)
             f32x2 PA = acc_a, PH = acc_h;
             if (!(SC_WHATIF & 512)) wave_scan_fwd(PA, PH);
@@ -248,13 +240,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             if (lane == np) carry = newc;
             SC_TIME(3);  // wave scan + carry
             cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
+            if constexpr (!MO) {
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
                 const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
-                const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]}
-                                 : (SC_FWD_CPRE != 0 ? cpre[i / 2] : *(const f32x4*)(tC + 2 * i));
+                const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]} : *(const f32x4*)(tC + 2 * i);
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
+            }
             }
             SC_TIME(4);  // output phase (C tile reads)
             if (more) {
@@ -265,6 +258,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             if (((tix + 1) & (AHEAD - 1)) == 0) __syncthreads();
             SC_TIME(6);  // barrier
         }
+        if constexpr (MO) continue;  // no output of a map-only pass
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) y[i] = y2[i][0] + y2[i][1];
         if (z_row) {
@@ -312,7 +306,9 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
     ScanFwdSets ks;
     for (int i = 0; i < nsets; ++i) {
         const cad_scan_args* a = &sets[i];
-        CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && a->out);
+        CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && (a->out || a->map_only));
+        CAD_CHECK_ARG(!a->map_only || (a->hT && a->sum_dt));
+        CAD_CHECK_ARG(a->map_only == sets[0].map_only);
         CAD_CHECK_ARG(a->E > 0 && a->SB > 0 && a->L > 0 && a->N > 0 && a->N <= SC_NMAX);
         CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB && a->SB <= 65535);
         CAD_CHECK_ARG(a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L && a->N == sets[0].N &&
@@ -330,10 +326,15 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const size_t shmem = (size_t)SC_RING_FWD * 2 * SC_TILE(SC_S) * sizeof(float) +
                          ((SC_FWD_DMA && vec && a->dtype == CAD_BF16 && SC_S == 16) ? PRE_BYTES : 0);
-#define SC_FWD_LAUNCH(T, V)                                                                                         \
-    do {                                                                                                            \
-        SC_BIG_LDS((scan_fwd_kernel<T, V>), shmem);                                                             \
-        CAD_LAUNCH((scan_fwd_kernel<T, V>), grid, block, shmem, stream, ks);                                        \
+#define SC_FWD_LAUNCH(T, V)                                                                  \
+    do {                                                                                     \
+        if (a->map_only) {                                                                   \
+            SC_BIG_LDS((scan_fwd_kernel<T, V, true>), shmem);                                \
+            CAD_LAUNCH((scan_fwd_kernel<T, V, true>), grid, block, shmem, stream, ks);       \
+        } else {                                                                             \
+            SC_BIG_LDS((scan_fwd_kernel<T, V, false>), shmem);                               \
+            CAD_LAUNCH((scan_fwd_kernel<T, V, false>), grid, block, shmem, stream, ks);      \
+        }                                                                                    \
     } while (0)
     if (a->dtype == CAD_F32) {
         if (vec)

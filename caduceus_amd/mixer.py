@@ -112,6 +112,16 @@ _SHARED_GATE = os.environ.get("CADUCEUS_AMD_SHARED_GATE", "1") != "0"
 _FUSED_SOFTPLUS = os.environ.get("CADUCEUS_AMD_FUSED_SOFTPLUS", "1") != "0"
 
 
+# BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
+# set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
+_FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
+
+
+def set_fp8_in_proj(on: bool) -> None:
+    global _FP8_IN_PROJ
+    _FP8_IN_PROJ = bool(on)
+
+
 def prepare_step_cache(pairs, act: torch.dtype) -> None:
     """Compute-dtype copies of every layer's projection weights and A = -exp(A_log), for ALL layers at once with
     multi-tensor (foreach) launches -- instead of ten tiny cast / exp / neg kernels per layer per step
@@ -134,6 +144,8 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
     torch._foreach_neg_(negA)
     for i, (mf, ps, out) in enumerate(owners):
         mf._cad_step_cache = {"versions": [(id(p), p._version) for p in ps], "w": out, "A": (negA[2 * i], negA[2 * i + 1])}
+        if _FP8_IN_PROJ and act == torch.bfloat16 and ops.fp8_proj_supported(out[0], out[0].shape[1]):
+            mf._cad_step_cache["w_in_fp8"] = ops.quant_weight_fp8(ps[0])  # from the fp32 master weight, once per step
 
 
 def _cached(mf, params):
@@ -159,7 +171,12 @@ class BiMambaMixerFn(torch.autograd.Function):
             cache = None
         w_in = cache["w"][0] if cache else W_in.to(act)
         w_out = cache["w"][1] if cache else W_out.to(act)
-        if ops.proj_supported(x2d, Dm):  # bf16: our W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
+        if _FP8_IN_PROJ and act == torch.bfloat16 and ops.fp8_proj_supported(x2d, Dm):
+            # fp8 matrix cores: per-token e4m3 activations x per-row e4m3 weights, fp32 accumulation, bf16 channel-major output
+            wq, sw = cache["w_in_fp8"] if (cache and "w_in_fp8" in cache) else ops.quant_weight_fp8(W_in)
+            xq, sx = ops.quant_rows_fp8(x2d)
+            xz = ops.proj_wxT_fp8(wq, sw, xq, sx).view(2 * E, SB, Lq)
+        elif ops.proj_supported(x2d, Dm):  # bf16: our W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
             xz = ops.proj_wxT(w_in, x2d).view(2 * E, SB, Lq)
         else:
             xz = torch.mm(w_in, x2d.t()).view(2 * E, SB, Lq)
@@ -193,39 +210,42 @@ class BiMambaMixerFn(torch.autograd.Function):
                 fused_sp.append(False)
             A = cache["A"][i] if cache else -torch.exp(A_log.float())
             sets.append((xc, delta, A, dbc, Dp.float().contiguous(), dt_bias.float().contiguous(), wf, bf, w_x, w_dt))
-        # both parameter sets in one scan launch
+        # both parameter sets in one scan launch; k > 1: every row cut into k segments along L (ops.lsplit_factor) when the
+        # launch would otherwise leave CUs idle (Caduceus-Ph at batch 1)
+        k = ops.lsplit_factor(E, SB, Lq, 2)
         args = (L.ScanArgs * 2)()
         outs, states = [], []
         ycat = torch.empty((2 * E, SB, Lq), dtype=act, device=x2d.device)  # [y_f ; y_r]: one out_proj GEMM with K = 2E
         for i, (xc, delta, A, dbc, Df, bfz, *_rest) in enumerate(sets):
             N, R = A.shape[1], dbc.shape[0] - 2 * A.shape[1]
             out = ycat[i * E:(i + 1) * E]
-            state = torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=xc.device)
+            state = torch.empty((lib.cad_scan_state_floats(E, SB * k, Lq // k, N),), dtype=torch.float32, device=xc.device)
             Bm, Cm = dbc[R:R + N], dbc[R + N:]
             stream = L.stream_and_check(xc, delta, A, Bm, Cm, Df, z, bfz, out, state)
             args[i] = L.ScanArgs(L.ptr(xc), L.ptr(delta), L.ptr(A), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bfz),
-                                 L.ptr(out), L.ptr(state), SB, Lq, split, E, N, dirs[i][0], dirs[i][1],
+                                 L.ptr(out), L.ptr(state), SB * k, Lq // k, split * k, E, N, dirs[i][0], dirs[i][1],
                                  L.dtype_code(act))
             args[i].delta_is_dt = int(fused_sp[i])
             outs.append(out)
             states.append(state)
-        L.check(lib.cad_scan_fwd_multi(args, 2, stream), "cad_scan_fwd_multi")
+        _keep, seg_P = ops.scan_fwd_launch(lib, args, 2, stream, k, [st[2] for st in sets], dirs, split)
         y_f, y_r = outs
         out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
         keep = [x2d, xz, w_in, w_out, ycat]
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt = sets[i]
             keep += [xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, states[i], ps[7 * i + 5]]
-        ctx.save_for_backward(*keep)
+        ctx.save_for_backward(*keep, *seg_P)
         ctx.meta = (SB, Lq, split, [tuple(None if p is None else (p.dtype, p.shape) for p in ps[7 * i:7 * i + 7])
-                                    for i in range(2)], W_in.dtype, W_out.dtype, tuple(fused_sp))
+                                    for i in range(2)], W_in.dtype, W_out.dtype, tuple(fused_sp), k)
         return out2d
 
     @staticmethod
     def backward(ctx, dout2d):
         lib = L.get_lib()
         x2d, xz, w_in, w_out, ycat, *rest = ctx.saved_tensors
-        SB, Lq, split, pmeta, win_dt, wout_dt, fused_sp = ctx.meta
+        SB, Lq, split, pmeta, win_dt, wout_dt, fused_sp, k = ctx.meta
+        seg_P, rest = (rest[24:], rest[:24]) if k > 1 else ([], rest)
         act = x2d.dtype
         T, Dm = x2d.shape
         E = xz.shape[0] // 2
@@ -268,13 +288,13 @@ class BiMambaMixerFn(torch.autograd.Function):
             args[i] = L.ScanBwdArgs(L.ptr(xc), L.ptr(delta), L.ptr(A), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
                                     L.ptr(bfz), L.ptr(dy), L.ptr(y_f if i == 0 else y_r), L.ptr(state), L.ptr(du),
                                     L.ptr(ddelta), L.ptr(dz), L.ptr(dA),
-                                    L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
+                                    L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB * k, Lq // k, split * k, E, N,
                                     dirs[i][0], dirs[i][1], L.dtype_code(act), npart, None, None,
                                     L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None, L.ptr(fix_list[i]),
                                     L.ptr(fix_cnt[i]), L.ptr(dxz[E:]) if (_SHARED_GATE or i == 0) else L.ptr(dz))
             args[i].delta_is_dt = int(fused_sp[i])
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
-        L.check(lib.cad_scan_bwd_multi(args, 2, stream), "cad_scan_bwd_multi")
+        _keep = ops.scan_bwd_launch(lib, args, 2, stream, k, seg_P, dirs, split)
         L.check(lib.cad_scan_bwd_gate_fix(args, 2, stream), "cad_scan_bwd_gate_fix")  # no-op unless some z == 0 exactly
         grads, dxcs, part = [], [], []
         for i in range(2):

@@ -8,6 +8,7 @@ memory, streams and the autograd graph; all arithmetic of these ops happens in t
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -169,6 +170,102 @@ def causal_conv1d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
 # ------------------------------------------------------------------------------------------------------------------
 # selective scan
 # ------------------------------------------------------------------------------------------------------------------
+# ---- L-split (two-pass) scans on one GPU --------------------------------------------------------------------------------
+# A scan launch has ceil(E / 8) * rows * sets workgroups -- 256 for Caduceus-PS at batch 1, i.e. one per CU, but only 128 for
+# Caduceus-Ph or a uni-directional model at batch 1.  When fewer than ~one workgroup per CU exist,
+# every row is cut into k segments along L, presented to the SAME kernels as rows (E, SB * k, L / k) of the same buffers:
+#   pass 1 (cheap kernel modes `map_only` / `carry_only`): each segment's affine state map from a zero entry state,
+#   composition of the k maps per row in the row's own direction (a few element-wise launches on (E, SB * k, N) tensors),
+#   pass 2 (the full kernels) from the true entry states (h0 / dhT of the scan C-ABI).
+# The same carries and composition chain segments ACROSS ranks in caduceus_amd/seqpar.py.
+def lsplit_factor(E: int, SB: int, Lq: int, nsets: int) -> int:
+    env = os.environ.get("CADUCEUS_AMD_LSPLIT", "")
+    chunk = int(L.get_lib().cad_scan_chunk_len())
+    if env:  # forced (tests, A/B runs): segments only have to be whole forward chunks
+        k = max(1, int(env))
+        return k if Lq % (k * chunk) == 0 else 1
+    ok = lambda k: Lq % (k * chunk) == 0 and Lq // k >= 8 * chunk
+    wgs = ((E + 7) // 8) * SB * nsets
+    k = 1
+    while wgs * 2 * k <= 256 and ok(2 * k):
+        k *= 2
+    return k
+
+
+def compose_segments(P, S, k: int, split: int, rev_lo: int, rev_hi: int, towards_end: bool):
+    """P, S: (E, SB * k, N) maps  v -> P * v + S  of the k segments of every row (segment q of row r is row r * k + q).
+    Returns the value ENTERING every segment when the chain starts from zero at the row's logical start
+    (towards_end=False: forward states) or at its logical end (towards_end=True: state gradients)."""
+    E, SBk, N = S.shape
+    SB = SBk // k
+    P4, S4 = P.view(E, SB, k, N), S.view(E, SB, k, N)
+    out = torch.zeros_like(S4)
+    for rows, rev in ((slice(0, split), rev_lo), (slice(split, SB), rev_hi)):
+        if rows.start >= rows.stop:
+            continue
+        ascending = (rev == 0) != towards_end
+        order = list(range(k)) if ascending else list(range(k - 1, -1, -1))
+        v = None
+        for j, q in enumerate(order):
+            if v is not None:
+                out[:, rows, q] = v
+            if j + 1 < k:
+                v = S4[:, rows, q] if v is None else P4[:, rows, q] * v + S4[:, rows, q]
+    return out.view(E, SBk, N)
+
+
+def scan_fwd_launch(lib, args, nsets: int, stream, k: int, As, dirs, split: int):
+    """cad_scan_fwd_multi on argument structs that already describe the k-way reshaped problem (SB * k rows of L / k).
+    k > 1: runs pass 1 (map_only), composes the entry states and points args[i].h0 at them.  Returns (keep-alive tensors,
+    [P_i]) -- P_i = exp(A * sum_dt) per segment, which the backward needs again."""
+    keep, Ps = [], []
+    if k > 1:
+        E, SBk, N = args[0].E, args[0].SB, args[0].N
+        dev = As[0].device
+        p1 = (L.ScanArgs * nsets)()
+        hTs, sdts = [], []
+        for i in range(nsets):
+            C.memmove(C.byref(p1[i]), C.byref(args[i]), C.sizeof(L.ScanArgs))
+            hT = torch.empty((E, SBk, N), dtype=torch.float32, device=dev)
+            sdt = torch.empty((E, SBk), dtype=torch.float32, device=dev)
+            p1[i].map_only, p1[i].out, p1[i].chunk_state, p1[i].z = 1, None, None, None
+            p1[i].h0, p1[i].hT, p1[i].sum_dt = None, L.ptr(hT), L.ptr(sdt)
+            hTs.append(hT), sdts.append(sdt)
+        L.check(lib.cad_scan_fwd_multi(p1, nsets, stream), "cad_scan_fwd_multi (map pass)")
+        for i in range(nsets):
+            P = torch.exp(As[i].unsqueeze(1) * sdts[i].unsqueeze(-1))
+            h0 = compose_segments(P, hTs[i], k, split, dirs[i][0], dirs[i][1], towards_end=False).contiguous()
+            args[i].h0 = L.ptr(h0)
+            keep.append(h0)
+            Ps.append(P)
+    L.check(lib.cad_scan_fwd_multi(args, nsets, stream), "cad_scan_fwd_multi")
+    return keep, Ps
+
+
+def scan_bwd_launch(lib, args, nsets: int, stream, k: int, Ps, dirs, split: int):
+    """cad_scan_bwd_multi on k-way reshaped argument structs; k > 1: pass 1 (carry_only) + composition of the state
+    gradients entering every segment (args[i].dhT)."""
+    keep = []
+    if k > 1:
+        E, SBk, N = args[0].E, args[0].SB, args[0].N
+        dev = Ps[0].device
+        p1 = (L.ScanBwdArgs * nsets)()
+        gs = []
+        for i in range(nsets):
+            C.memmove(C.byref(p1[i]), C.byref(args[i]), C.sizeof(L.ScanBwdArgs))
+            g = torch.empty((E, SBk, N), dtype=torch.float32, device=dev)
+            p1[i].carry_only, p1[i].dhT, p1[i].dh0 = 1, None, L.ptr(g)
+            p1[i].dz, p1[i].out2, p1[i].gate_fix_list, p1[i].gate_fix_count = None, None, None, None
+            gs.append(g)
+        L.check(lib.cad_scan_bwd_multi(p1, nsets, stream), "cad_scan_bwd_multi (carry pass)")
+        for i in range(nsets):
+            dhT = compose_segments(Ps[i], gs[i], k, split, dirs[i][0], dirs[i][1], towards_end=True).contiguous()
+            args[i].dhT = L.ptr(dhT)
+            keep.append(dhT)
+    L.check(lib.cad_scan_bwd_multi(args, nsets, stream), "cad_scan_bwd_multi")
+    return keep
+
+
 def gate_fix_buffers(lib, u, N):
     """Worklist (int64 slots) + zeroed counter (int32) for the exact gate gradient at z == 0 (cad_scan_bwd_gate_fix)."""
     E, SB, Lq = u.shape
@@ -197,28 +294,30 @@ class _ScanMulti(torch.autograd.Function):
                 raise TypeError("selective_scan: u, delta, B, C, z must share one dtype")
             E, SB, Lq = u.shape
             N = A.shape[1]
+            k = lsplit_factor(E, SB, Lq, nsets)  # same shapes in every set -> same k
             Af, Df, bf = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
             out = torch.empty_like(u)
-            state = (torch.empty((lib.cad_scan_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
+            state = (torch.empty((lib.cad_scan_state_floats(E, SB * k, Lq // k, N),), dtype=torch.float32, device=u.device)
                      if need_grad else None)
             stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, out, state)
             rl, rh = dirs[i]
             args[i] = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
-                                 L.ptr(out), L.ptr(state), SB, Lq, split, E, N, rl, rh, L.dtype_code(u.dtype))
+                                 L.ptr(out), L.ptr(state), SB * k, Lq // k, split * k, E, N, rl, rh, L.dtype_code(u.dtype))
             args[i].delta_is_dt = int(bool(delta_is_dt))
             sets.append((u, delta, Af, Bm, Cm, Df, bf, state, out))
             outs.append(out)
-        L.check(lib.cad_scan_fwd_multi(args, nsets, stream), "cad_scan_fwd_multi")
+        _keep, Ps = scan_fwd_launch(lib, args, nsets, stream, k, [s_[2] for s_ in sets], dirs, split)
         flat = [t for s_ in sets for t in s_]
-        ctx.save_for_backward(z, *flat)
+        ctx.save_for_backward(z, *flat, *Ps)
         ctx.meta = (split, dirs, nsets, [(t[2].dtype, t[5].dtype, t[6].dtype) for t in
-                                         [tensors[7 * i:7 * i + 7] for i in range(nsets)]], bool(delta_is_dt))
+                                         [tensors[7 * i:7 * i + 7] for i in range(nsets)]], bool(delta_is_dt), k)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
         z, *flat = ctx.saved_tensors
-        split, dirs, nsets, pdt, delta_is_dt = ctx.meta
+        split, dirs, nsets, pdt, delta_is_dt, k = ctx.meta
+        Ps, flat = (flat[9 * nsets:], flat[:9 * nsets]) if k > 1 else ([], flat)
         lib = L.get_lib()
         args = (L.ScanBwdArgs * nsets)()
         keep, res = [], []
@@ -237,13 +336,13 @@ class _ScanMulti(torch.autograd.Function):
             fix_list, fix_cnt = gate_fix_buffers(lib, u, N) if z is not None else (None, None)
             args[i] = L.ScanBwdArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z),
                                     L.ptr(bf), L.ptr(dout), L.ptr(fout), L.ptr(state), L.ptr(du), L.ptr(ddelta), L.ptr(dz),
-                                    L.ptr(dA), L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB, Lq, split, E, N,
-                                    rl, rh, L.dtype_code(u.dtype), npart, None, None, None, L.ptr(fix_list),
+                                    L.ptr(dA), L.ptr(dBC[0]), L.ptr(dBC[1]), L.ptr(dD), L.ptr(dbias), SB * k, Lq // k,
+                                    split * k, E, N, rl, rh, L.dtype_code(u.dtype), npart, None, None, None, L.ptr(fix_list),
                                     L.ptr(fix_cnt), L.ptr(dz))
             args[i].delta_is_dt = int(delta_is_dt)
             keep.append((dout, dBC, fix_list, fix_cnt))
             res.append([du, ddelta, dA, dBC, dD, dbias, dz])
-        L.check(lib.cad_scan_bwd_multi(args, nsets, stream), "cad_scan_bwd_multi")
+        keep.append(scan_bwd_launch(lib, args, nsets, stream, k, Ps, dirs, split))
         if z is not None:  # exact gate gradient where z == 0 (rare; the launch is a no-op otherwise)
             L.check(lib.cad_scan_bwd_gate_fix(args, nsets, stream), "cad_scan_bwd_gate_fix")
         grads = []
@@ -344,48 +443,6 @@ class _ScanStateful(torch.autograd.Function):
 def selective_scan_stateful(u, delta, A, Bm, Cm, D, z, delta_bias, h0, split: int, rev_lo: int, rev_hi: int):
     """Segment scan with state carries: returns (out, hT).  See _ScanStateful."""
     return _ScanStateful.apply(u, delta, A, Bm, Cm, D, z, delta_bias, h0, int(split), int(rev_lo), int(rev_hi))
-
-
-# ------------------------------------------------------------------------------------------------------------------
-# selective scan, token-major kernels
-# ------------------------------------------------------------------------------------------------------------------
-def scan_tm_forward(sets, z, split: int, dirs, save_state: bool = True):
-    """Raw (no autograd) token-major forward for 1 or 2 parameter sets in one launch sequence.
-    sets: list of (u, delta, A, BC, D, delta_bias) with u, delta: (SB, L, E) views whose last dim is contiguous (row
-    stride free), BC: fp32 (SB, L, >= 2N) view holding B_t | C_t in its first 2N columns, A: (E, N).
-    z: (SB, L, E) view or None (shared gate).  Returns [(out, state, scratch)] per set."""
-    lib = L.get_lib()
-    nsets = len(sets)
-    args = (L.ScanTmArgs * nsets)()
-    res, keep = [], []
-
-    def _ld(t):
-        ld = t.stride(1) if t.shape[1] > 1 else max(t.stride(1), t.shape[2])  # size-1 dims carry arbitrary strides
-        if t.stride(-1) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld):
-            raise ValueError("scan_tm: activations must be (SB, L, E) views with unit channel stride and dense rows")
-        return ld
-
-    for i, (u, delta, A, BC, D, bias) in enumerate(sets):
-        SB, Lq, E = u.shape
-        N = A.shape[1]
-        if delta.dtype != u.dtype or (z is not None and z.dtype != u.dtype):
-            raise TypeError("scan_tm: u, delta, z must share one dtype")
-        if BC.dtype != torch.float32:
-            raise TypeError("scan_tm: BC must be fp32")
-        Af, Df, bf = A.float().contiguous(), D.float().contiguous(), bias.float().contiguous()
-        out = torch.empty((SB, Lq, E), dtype=u.dtype, device=u.device)
-        state = (torch.empty((lib.cad_scan_tm_state_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
-                 if save_state else None)
-        scratch = torch.empty((lib.cad_scan_tm_scratch_floats(E, SB, Lq, N),), dtype=torch.float32, device=u.device)
-        stream = L.stream_and_check(u, delta, z, Af, BC, Df, bf, out, state, scratch, contiguous=False)
-        rl, rh = dirs[i]
-        args[i] = L.ScanTmArgs(L.ptr(u), L.ptr(delta), L.ptr(z), L.ptr(Af), L.ptr(BC), L.ptr(Df), L.ptr(bf), L.ptr(out),
-                               L.ptr(state), L.ptr(scratch), SB, Lq, split, _ld(u), _ld(delta),
-                               0 if z is None else _ld(z), _ld(BC), _ld(out), E, N, rl, rh, L.dtype_code(u.dtype))
-        keep.append((Af, Df, bf))
-        res.append((out, state, scratch))
-    L.check(lib.cad_scan_tm_fwd_multi(args, nsets, stream), "cad_scan_tm_fwd_multi")
-    return res
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -499,4 +556,56 @@ def proj_wx(W: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None
     a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0), L.ptr(acc),
                    0 if acc is None else acc.stride(0), L.ptr(softplus_bias), 0 if softplus_bias is None else 1)
     L.check(L.get_lib().cad_proj_wx(C.byref(a), stream), "cad_proj_wx")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) in_proj: BASELINE configs[4] "fp8 MFMA projections"
+# ------------------------------------------------------------------------------------------------------------------
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+def fp8_proj_supported(t: torch.Tensor, K: int) -> bool:
+    return t.dtype in (torch.bfloat16, torch.float32) and bool(L.get_lib().cad_proj_fp8_supported(int(K)))
+
+
+def quant_rows_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x (T, K) fp32 / bf16 -> (q (T, K) e4m3 bytes as uint8, scale (T) fp32) with x ~ q * scale[:, None]: one scale per token
+    (cad_quant_rows_fp8), so a token's quantisation does not depend on its position."""
+    T, K = x.shape
+    if x.stride(1) != 1:
+        raise ValueError("quant_rows_fp8: unit inner stride")
+    q = torch.empty((T, K), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((T,), dtype=torch.float32, device=x.device)
+    stream = L.stream_and_check(x, q, scale, contiguous=False)
+    a = L.QuantFp8Args(L.ptr(x), L.ptr(q), L.ptr(scale), T, K, x.stride(0), q.stride(0), L.dtype_code(x.dtype))
+    L.check(L.get_lib().cad_quant_rows_fp8(C.byref(a), stream), "cad_quant_rows_fp8")
+    return q, scale
+
+
+def quant_weight_fp8(W: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """W (M, K) -> (e4m3 bytes as uint8, per-row scale (M) fp32).  Weights change once per optimizer step: plain torch ops."""
+    w = W.detach().float()
+    s = (w.abs().amax(dim=1) / FP8_MAX).clamp_min(1e-30)
+    q = (w / s[:, None]).clamp_(-FP8_MAX, FP8_MAX).to(FP8).view(torch.uint8)
+    return q.contiguous(), s.contiguous()
+
+
+def proj_wxT_fp8(Wq: torch.Tensor, sw: torch.Tensor, Xq: torch.Tensor, sx: torch.Tensor,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (M, T) channel-major bf16 = (Wq (M, K) @ Xq (T, K)^T) * sw[:, None] * sx[None, :] on the fp8 matrix cores
+    (cad_proj_wxT_fp8); Wq / Xq: e4m3 bytes (uint8 tensors), sw / sx: fp32 scales."""
+    M, K = Wq.shape
+    T = Xq.shape[0]
+    if Xq.shape[1] != K or Wq.dtype != torch.uint8 or Xq.dtype != torch.uint8 or Wq.stride(1) != 1 or Xq.stride(1) != 1:
+        raise ValueError("proj_wxT_fp8: Wq (M, K), Xq (T, K) uint8 (e4m3 bytes) with unit inner stride")
+    if sw.dtype != torch.float32 or sx.dtype != torch.float32 or sw.numel() != M or sx.numel() != T:
+        raise ValueError("proj_wxT_fp8: sw (M), sx (T) fp32")
+    if out is None:
+        out = torch.empty((M, T), dtype=torch.bfloat16, device=Xq.device)
+    stream = L.stream_and_check(Wq, Xq, sw, sx, out, contiguous=False)
+    a = L.ProjFp8Args(L.ptr(Wq), L.ptr(Xq), L.ptr(sw), L.ptr(sx), L.ptr(out), T, M, K, Wq.stride(0), Xq.stride(0),
+                      out.stride(0))
+    L.check(L.get_lib().cad_proj_wxT_fp8(C.byref(a), stream), "cad_proj_wxT_fp8")
     return out

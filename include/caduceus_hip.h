@@ -199,6 +199,9 @@ typedef struct {
     float* sum_dt;
     int delta_is_dt;   /* 1: `delta` already holds dt = softplus(delta_raw + delta_bias) (written by cad_proj_wx with
                         * act = CAD_ACT_SOFTPLUS_BIAS); delta_bias is ignored */
+    int map_only;      /* 1: only the row's affine state map is wanted -- hT (from h0, default 0) and sum_dt are written, `out`
+                        * and chunk_state are not touched (may be NULL), C / D / z are not read.  Pass 1 of an L-split scan:
+                        * the segments of a row are presented as rows (E, SB * k, L / k) of the same buffers. */
 } cad_scan_args;
 int cad_scan_fwd(const cad_scan_args* a, void* stream);
 /* Same, for nsets (1 or 2) independent parameter sets of identical shape in ONE launch -- the mamba_fwd and mamba_rev
@@ -255,6 +258,10 @@ typedef struct {
     void* gate_fix_dz;
     int delta_is_dt;   /* as in cad_scan_args; ddelta / ddelta_bias are still the gradients w.r.t. delta_raw / the bias:
                         * d(dt) * sigmoid(delta_raw + bias) = d(dt) * (1 - exp(-dt)) */
+    int carry_only;    /* 1: only dh0 (from dhT, default 0) is wanted -- the reverse recurrence of the state gradient alone
+                        * (exp, C * dy, one chain per item and state); no other output is written, B / chunk_state / out are
+                        * not read (du, ddelta, dA, dB, dC, dD, ddelta_bias, chunk_state may be NULL).  Pass 1 of an L-split
+                        * backward (see map_only). */
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
@@ -263,45 +270,6 @@ int64_t cad_scan_gate_fix_entries(int E, int64_t SB, int64_t L);
 int cad_scan_bwd_partials(int E);
 /* dst[i] = sum_k src[k*n + i], k < n_partials (fp32 accumulation); src and dst in dtype (fp32 or bf16). */
 int cad_reduce_partials(const void* src, int n_partials, int64_t n, void* dst, int dtype, void* stream);
-
-/* ---------------------------------------------------------------------------------------------------------
- * Selective SSM scan, TOKEN-MAJOR ("tm") kernels: same mathematics and the same reference call sites as
- * cad_scan_fwd / cad_scan_bwd above (selective_scan_cuda.fwd/.bwd behind mamba_ssm.Mamba.forward,
- * modeling_caduceus.py:128,130), for activations laid out (SB, L, E) with E contiguous -- the layout the in_proj /
- * dt_proj GEMMs write and out_proj reads without any transpose.  One lane owns one or two channels and walks its
- * chunk sequentially with all N states in registers (no cross-lane scan, no LDS); B_t / C_t are wave-uniform and are
- * fetched with scalar loads.
- *   u, delta, z, out : (SB, L, E) dtype, row strides ld_* in ELEMENTS (z / u may be column slices of the
- *                      in_proj output, ld = 2E).
- *   BC               : fp32 (SB, L, ld_bc): columns [0, N) = B_t, [N, 2N) = C_t (the fp32 x_proj output, offset
- *                      by dt_rank columns).
- *   state            : fp32 [SB][ceil(L / cad_scan_tm_block_len())][N][E]: the running state entering every
- *                      block, written by the forward for the backward (NULL: not saved).
- *   scratch          : fp32, cad_scan_tm_scratch_floats() elements: per-chunk aggregates, then chunk-start states.
- * Rows [0, split) run in direction rev_lo, rows [split, SB) in rev_hi, as an exact mirror (bit-exact
- * RC-equivariance). */
-typedef struct {
-    const void* u;
-    const void* delta;
-    const void* z;
-    const float* A;
-    const float* BC;
-    const float* D;
-    const float* delta_bias;
-    void* out;
-    float* state;
-    float* scratch;
-    int64_t SB, L, split;
-    int64_t ld_u, ld_delta, ld_z, ld_bc, ld_out;
-    int E, N;
-    int rev_lo, rev_hi;
-    int dtype;
-} cad_scan_tm_args;
-int cad_scan_tm_fwd(const cad_scan_tm_args* a, void* stream);
-int cad_scan_tm_fwd_multi(const cad_scan_tm_args* sets, int nsets, void* stream);
-int64_t cad_scan_tm_block_len(void);
-int64_t cad_scan_tm_state_floats(int E, int64_t SB, int64_t L, int N);
-int64_t cad_scan_tm_scratch_floats(int E, int64_t SB, int64_t L, int N);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Dense projections of the mixer on the matrix cores (bf16 MFMA, fp32 accumulation).   Replace the `in_proj` /
@@ -338,6 +306,38 @@ int cad_proj_wx_supported(int K, int64_t T);
 /* cad_proj_wx also takes thin M / deep K products without addend (M <= 64, K a multiple of 64 up to 1024, T % 8 == 0; ldo % 4):
  * x_proj (M = dt_rank + 2 d_state, K = d_inner; `x_proj` inside mamba_inner_fn) and d(dt_lr) = W_dt^T . d(delta). */
 int cad_proj_wx_thin_supported(int M, int K, int64_t T);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3) projections -- BASELINE configs[4] "fp8 MFMA projections": the same `in_proj` nn.Linear call of
+ * mamba_ssm.Mamba.forward (modeling_caduceus.py:128,130) on v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation.
+ * cad_quant_rows_fp8:  q (T, K) e4m3 = x (T, K) / scale[t],  scale[t] = max|x[t, :]| / 448 (1 for an all-zero row), one
+ *   scale per TOKEN, so a token's quantisation -- hence its projection -- does not depend on its position or its batch
+ *   (RC-equivariance stays exact).  x in `dtype` (fp32 / bf16), rows contiguous (ldx elements apart).
+ * cad_proj_wxT_fp8:    out (M, T) channel-major bf16 = (Wq (M, K) . Xq (T, K)^T) * sw[m] * sx[t]
+ *   Wq / Xq e4m3 (rows ldw / ldx BYTES apart, multiples of 16), sw (M) / sx (T) fp32 de-quantisation scales.
+ *   K in {256, 512} (cad_proj_fp8_supported); any M, T. */
+typedef struct {
+    const void* x;
+    void* q;
+    float* scale;
+    int64_t T;
+    int K;
+    int64_t ldx, ldq;
+    int dtype;
+} cad_quant_fp8_args;
+int cad_quant_rows_fp8(const cad_quant_fp8_args* a, void* stream);
+typedef struct {
+    const void* Wq;
+    const void* Xq;
+    const float* sw;
+    const float* sx;
+    void* out;
+    int64_t T;
+    int M, K;
+    int64_t ldw, ldx, ldo;
+} cad_proj_fp8_args;
+int cad_proj_wxT_fp8(const cad_proj_fp8_args* a, void* stream);
+int cad_proj_fp8_supported(int K);
 
 /* ---------------------------------------------------------------------------------------------------------
  * RCPS LM head + cross-entropy.   Replaces RCPSLMHead.forward (modeling_rcps.py:233-246), logits.float()

@@ -15,8 +15,8 @@ sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-REL1_BOUND = 0.12   # configs[1], 16 layers bf16 (calibrated below)
-REL2_BOUND = 0.05   # configs[2] layer shape, 1 layer bf16
+REL1_BOUND = 0.06   # configs[1], 16 layers bf16: measured worst 0.022 (a layer-3 x_proj weight), median 0.007 (MI355X, round 3)
+REL2_BOUND = 0.025  # configs[2] layer shape, 1 layer bf16: measured 0.004 .. 0.009 over all 19 parameters
 
 
 @pytest.fixture(autouse=True)
@@ -103,8 +103,8 @@ def test_config1_ph_d256_n16_L1024_bf16_vs_oracle():
             errs[k] = float((p.grad.float().cpu() - want).norm() / want.norm())
     worst = max(errs, key=errs.get)
     print("config1 gradient relative-norm errors: worst", worst, errs[worst], "median", sorted(errs.values())[len(errs) // 2])
-    # per-parameter relative error norms of the bf16 16-layer backward against the fp32 oracle (measured on the MI355X in round 3:
-    # median REL1_MEDIAN, worst REL1_WORST); cos > 0.97 of earlier rounds corresponds to 0.25 here
+    # per-parameter relative error norms of the bf16 16-layer backward against the fp32 oracle (bound = ~3x the worst measured
+    # value, see REL1_BOUND); the cos > 0.97 of earlier rounds corresponds to 0.25 on this scale
     for k, e in errs.items():
         assert e < REL1_BOUND, (k, e)
 
@@ -225,3 +225,96 @@ def test_config3_bucketed_allreduce_through_rccl():
         os.environ.pop("CADUCEUS_DP_FORCE_COLLECTIVE", None)
         if created:
             dist.destroy_process_group()
+
+
+def test_config4_scan_d512_L262144_channel_slice_vs_c_oracle():
+    """configs[4] layer shape: the scans at L = 262144 with N = 16 on a 32-channel slice of the E = 1024 channels (both directions,
+    bf16): forward and every gradient against oracle/cad_oracle.c -- the kernels' arithmetic does not depend on E beyond the
+    cross-channel dB / dC sums, which the slice exercises over four workgroups."""
+    from caduceus_amd import ops
+    from oracle import oracle_ops
+    E, SB, N, Lq, dtype = 32, 2, 16, 262144, torch.bfloat16
+    g = torch.Generator().manual_seed(44)
+    r = lambda *sh: torch.randn(*sh, generator=g)
+    t = dict(u=r(E, SB, Lq), delta=0.5 * r(E, SB, Lq), A=-(0.5 + 15.5 * torch.rand(E, N, generator=g)), B=r(N, SB, Lq),
+             C=r(N, SB, Lq), D=r(E), z=r(E, SB, Lq), bias=r(E) - 4.0)
+    order = ("u", "delta", "A", "B", "C", "D", "z", "bias")
+    act = {"u", "delta", "B", "C", "z"}
+    for k in act:
+        t[k] = t[k].to(dtype).float()
+    ins = [t[k].to(DEV).to(dtype if k in act else torch.float32).requires_grad_(True) for k in order]
+    out = ops.selective_scan(*ins, 1, 0, 1)
+    w = torch.randn(E, SB, Lq, generator=torch.Generator().manual_seed(9))
+    (out.float() * w.to(DEV)).sum().backward()
+    refs = [t[k].clone().requires_grad_(True) for k in order]
+    u, d, A, B, C, D, z, b = refs
+    rows = []
+    for sb in range(SB):
+        f = (lambda x: x.flip(-1)) if sb == 1 else (lambda x: x)
+        bm = lambda x: f(x[:, sb]).unsqueeze(0)
+        rows.append(f(oracle_ops.selective_scan_c(bm(u), bm(d), A, bm(B), bm(C), D, bm(z), b)[0]))
+    ref = torch.stack(rows, 1)
+    (ref * w).sum().backward()
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), rtol=3e-2, atol=5e-2)
+    for k, a, r_ in zip(order, ins, refs):
+        scale = max(1.0, float(r_.grad.abs().max())) * (4 if k in ("A", "D", "bias") else 1)
+        torch.testing.assert_close(a.grad.float().cpu(), r_.grad, rtol=3e-2, atol=5e-2 * scale, msg=lambda m, k=k: f"d{k}: {m}")
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_config4_model_d512_L262144_rc_equivariance(fp8):
+    """configs[4]: Caduceus-PS d_model=512 n_layer=16 at seqlen 262144 under bf16 autocast, with the bf16 and with the fp8 (e4m3)
+    in_proj: the logits of the reverse-complement input are the RC of the logits BIT-EXACTLY (per-token scales keep the fp8
+    projection position-independent), the loss agrees, and the fp8 logits stay within the stated tolerance of the bf16 ones."""
+    from bench import COMP, make_config, synthetic_batch
+    from caduceus_amd import CaduceusForMaskedLM, mixer
+    torch.manual_seed(0)
+    model = CaduceusForMaskedLM(make_config(512, 16)).to(DEV).eval()
+    Lq = 262144
+    ids, labels = synthetic_batch(torch.Generator().manual_seed(3), 1, Lq, DEV)
+    comp = torch.tensor([COMP.get(i, i) for i in range(16)], device=DEV)
+    rc = lambda x: comp[x.flip(-1)]
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            base = model(ids, labels=labels) if fp8 else None
+            mixer.set_fp8_in_proj(fp8)
+            a = model(ids, labels=labels)
+            b = model(rc(ids), labels=rc(labels))
+    finally:
+        mixer.set_fp8_in_proj(False)
+    assert torch.isfinite(a.logits).all()
+    assert torch.equal(a.logits, b.logits.flip(1)[..., comp])
+    assert abs(float(a.loss) - float(b.loss)) < 1e-4 * abs(float(a.loss))
+    if fp8:
+        rel = float((a.logits - base.logits).norm() / base.logits.norm())
+        print("config4 fp8 in_proj: relative logits error vs bf16", rel, "loss", float(a.loss), "vs", float(base.loss))
+        assert rel < 0.15 and abs(float(a.loss) - float(base.loss)) < 0.05 * float(base.loss)
+
+
+def test_ph_L131072_lsplit_training_step_matches_unsplit(monkeypatch):
+    """Caduceus-Ph at batch 1, seqlen 131072 (2 layers, bf16): 128 scan workgroups per launch -> ops.lsplit_factor cuts every row
+    in two and runs the two-pass L-split on the product path.  Logits, loss and every parameter gradient equal the un-split run
+    (CADUCEUS_AMD_LSPLIT=1) to bf16 summation-order rounding."""
+    from bench import make_config, synthetic_batch
+    from caduceus_amd import CaduceusForMaskedLM, ops
+    assert ops.lsplit_factor(512, 1, 131072, 2) == 2 and ops.lsplit_factor(512, 2, 131072, 2) == 1
+    torch.manual_seed(5)
+    model = CaduceusForMaskedLM(make_config(256, 2, rcps=False)).to(DEV).train()
+    ids, labels = synthetic_batch(torch.Generator().manual_seed(4), 1, 131072, DEV)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(ids, labels=labels)
+        out.loss.backward()
+        return out, {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    a, ga = run()
+    monkeypatch.setenv("CADUCEUS_AMD_LSPLIT", "1")
+    b, gb = run()
+    rel = float((a.logits - b.logits).norm() / b.logits.norm())
+    assert rel < 5e-3, rel
+    assert abs(float(a.loss) - float(b.loss)) < 1e-3 * abs(float(b.loss))
+    for k in ga:
+        e = float((ga[k].float() - gb[k].float()).norm() / gb[k].float().norm().clamp_min(1e-12))
+        assert e < 2e-2, (k, e)

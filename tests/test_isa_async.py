@@ -58,6 +58,12 @@ def _walk_to_wait(lines, labels, start, pending, where):
             if m:
                 i = labels[m.group(2)]
                 continue
+            # inverted layout of a guarded block: `s_cbranch_<cc> BLOCK ; s_branch SKIP` -- the fall-through is only the jump
+            # around the block, the conditional target is the block the prefetch's wait lives in
+            m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", line)
+            if m and re.match(r"s_branch\s+\.LBB\d+_\d+", lines[i + 1].strip()):
+                i = labels[m.group(1)]
+                continue
         i += 1
     raise AssertionError(f"{where}: no s_waitcnt vmcnt(0) found on the path after the prefetch")
 

@@ -97,3 +97,36 @@ def test_proj_wx_softplus_bias_epilogue(backend, M, K, T):
     torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=1.6e-2, atol=1e-6)
     with pytest.raises(Exception):
         ops.proj_wx(W.to(dev), X.to(dev), acc=out, softplus_bias=bias.to(dev))
+
+
+@pytest.mark.parametrize("case", [(256, 300, 130), (512, 2048 + 40, 200), (256, 1024, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_fp8_in_proj_quantisation_and_product(backend, case, dtype):
+    """configs[4]'s fp8 projection: cad_quant_rows_fp8 (per-token e4m3 quantisation) is held bit-for-bit to torch's own
+    float8_e4m3fn cast of x / scale, and cad_proj_wxT_fp8 to the fp64 product of the DE-QUANTISED operands (the only
+    difference left is fp32 accumulation order + the bf16 output rounding); against the UN-quantised product the relative error
+    norm stays below 6e-2 -- the stated tolerance of the fp8 path: e4m3 keeps 3 mantissa bits, i.e. an RMS rounding error of
+    2^-4 / sqrt(3) = 3.6 % per operand, 5 % per product, and a sum of K such products keeps that relative error."""
+    name, dev = backend
+    K, M, T = case
+    g = torch.Generator().manual_seed(K + T)
+    x = torch.randn(T, K, generator=g)
+    x[3] *= 30.0      # rows of very different magnitude: the per-token scale absorbs them
+    x[5] = 0.0        # an all-zero row (scale 1, zeros)
+    W = torch.randn(M, K, generator=g) / K ** 0.5
+    xd = x.to(dtype).to(dev)
+    q, sx = ops.quant_rows_fp8(xd)
+    xf = xd.float().cpu()
+    want_s = torch.where(xf.abs().amax(1) > 0, xf.abs().amax(1) * (1.0 / 448.0), torch.ones(T))
+    torch.testing.assert_close(sx.cpu(), want_s, rtol=1e-6, atol=0)
+    want_q = (xf * (1.0 / sx.cpu())[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), want_q)
+    Wq, sw = ops.quant_weight_fp8(W.to(dev))
+    out = ops.proj_wxT_fp8(Wq, sw, q, sx)
+    deq_w = Wq.cpu().view(torch.float8_e4m3fn).double() * sw.cpu().double()[:, None]
+    deq_x = q.cpu().view(torch.float8_e4m3fn).double() * sx.cpu().double()[:, None]
+    ref = deq_w @ deq_x.t()
+    torch.testing.assert_close(out.float().cpu().double(), ref, rtol=8e-3, atol=8e-3 * float(ref.abs().max()) / 16)
+    full = W.double() @ xf.double().t()
+    rel = float((out.float().cpu().double() - full).norm() / full.norm())
+    assert rel < 6e-2, rel
