@@ -86,7 +86,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     static_assert(!PACKED || SC_S == 8, "packed slab: two 4-item blocks per lane");
     // item vectors of the next chunk travel global -> LDS by DMA one chunk ahead (16-byte vectors: bf16, 8 items)
     constexpr bool PREF = SC_BWD_PREFETCH && PACKED && VEC && SC_S * sizeof(T) == 16;
-    char* pre = (char*)(accp + 2 * PK_BUF);  // [vector 0..5][wave][lane][16 bytes], behind the two slab buffers
+    // [vector 0..5][wave][lane][16 bytes], behind the two slab buffers (a carry-only pass has no slab: 68 KB of LDS in all, so two
+    // of its workgroups -- 92 VGPRs -- share a CU)
+    char* pre = CO ? (char*)acc : (char*)(accp + 2 * PK_BUF);
     const int lane = threadIdx.x & 63;
     // selection matrix of the MFMA flush (see PK_TILE): row i = lane & 15 picks element pi(i & 7) of every piece
     u32x4 selA = {0u, 0u, 0u, 0u};
@@ -516,18 +518,19 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }  // SC_WHATIF & 32
             } else {
                 constexpr int QT = 64 * SC_W / 4;     // threads per (tensor, state)
-                constexpr int FT = SC_CHUNK / QT;     // positions per thread (4 or 8)
+                constexpr int FT = SC_CHUNK / QT;     // positions per thread (2, 4 or 8)
+                constexpr int FV = FT < 4 ? FT : 4;   // ... stored FV at a time
                 const int t = threadIdx.x;
                 const int ten = t / (2 * QT), s = (t / QT) & 1, idx = t % QT;
                 const float* tile = acc + (SC_SLAB_BUFS == 2 ? buf : 0) * ACC_BUF + ten * ACC_TILE;
                 T* grow = (ten ? dCg : dBg) + ((int64_t)(n0 + s) * SB + sb) * L;
 #pragma unroll
-                for (int h4 = 0; h4 < FT; h4 += 4) {
+                for (int h4 = 0; h4 < FT; h4 += FV) {
                     const int tok = idx * FT + h4;
                     const int j = tok / SC_S, i0 = tok % SC_S;
-                    float v[4];
+                    float v[FV];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < FV; ++q) {
                         const float* src = tile + (i0 + q) * ACC_ISTR + j * 2 + s;
                         float sum = 0.f;
 #pragma unroll
@@ -539,15 +542,17 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         if (VEC) {
                             if (p < L) {
                                 if (rev) {
-                                    const float o[4] = {v[3], v[2], v[1], v[0]};
-                                    cad_cvt_store<T, 4>(grow + (L - p - 4), o);
+                                    float o[FV];
+#pragma unroll
+                                    for (int q = 0; q < FV; ++q) o[q] = v[FV - 1 - q];
+                                    cad_cvt_store<T, FV>(grow + (L - p - FV), o);
                                 } else {
-                                    cad_cvt_store<T, 4>(grow + p, v);
+                                    cad_cvt_store<T, FV>(grow + p, v);
                                 }
                             }
                         } else {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
+                            for (int q = 0; q < FV; ++q)
                                 if (p + q < L) grow[cad_phys(p + q, L, rev)] = from_f32<T>(v[q]);
                         }
                     }
@@ -738,7 +743,8 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
     const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
-    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF)) * sizeof(float) +
+    const size_t slab_floats = a->carry_only ? 0 : (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF);
+    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + slab_floats) * sizeof(float) +
                          (pref ? PRE_BYTES : 0);
 #define SC_BWD_LAUNCH(T, V)                                                                  \
     do {                                                                                     \

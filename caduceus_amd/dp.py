@@ -107,7 +107,13 @@ class BucketedGradReducer:
 
     def finish(self):
         """Call after backward: gathers the buckets whose last gradient never arrived (unused parameters), waits for the
-        outstanding all-reduces (and launches any that never triggered)."""
+        outstanding all-reduces (and launches any that never triggered).
+        Parameters that received no gradient keep a ZERO gradient (their bucket view is zeroed for the all-reduce and stays
+        attached), where DDP / Lightning leave `grad = None`: an optimizer with weight decay therefore still decays them.  All
+        parameters of the Caduceus models receive gradients, so the two coincide on this path."""
+        if not self.sync_enabled:
+            raise RuntimeError("BucketedGradReducer.finish() inside no_sync(): call it after the last micro-step, outside the "
+                               "context (the all-reduce would be skipped silently)")
         for bi in range(len(self.buckets)):
             if self._pending[bi] != 0:
                 self._gather(bi)

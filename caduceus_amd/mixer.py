@@ -139,11 +139,22 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
         dst += out
         alog += [mf.A_log.detach().float(), mr.A_log.detach().float()]
         owners.append((mf, ps + [mf.A_log, mr.A_log], out))
+    # the backward's transposed operands (W_out^T, W_dt^T, W_x^T per set) are made here too, once per step, instead of three
+    # `.t().contiguous()` launches per layer and backward
+    src_t, dst_t = [], []
+    for mf, ps, out in owners:
+        tr = [torch.empty((p.shape[1], p.shape[0]), dtype=act, device=p.device) for p in (ps[1], ps[2], ps[3], ps[4], ps[5])]
+        src_t += [p.detach().t() for p in (ps[1], ps[2], ps[3], ps[4], ps[5])]
+        dst_t += tr
+        out.append(tr)
     torch._foreach_copy_(dst, src)
+    torch._foreach_copy_(dst_t, src_t)
     negA = torch._foreach_exp(alog)
     torch._foreach_neg_(negA)
     for i, (mf, ps, out) in enumerate(owners):
-        mf._cad_step_cache = {"versions": [(id(p), p._version) for p in ps], "w": out, "A": (negA[2 * i], negA[2 * i + 1])}
+        tr = out.pop()  # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T]
+        mf._cad_step_cache = {"versions": [(id(p), p._version) for p in ps], "w": out, "A": (negA[2 * i], negA[2 * i + 1]),
+                              "wT": {"out": tr[0], "x": (tr[1], tr[3]), "dt": (tr[2], tr[4])}}
         if _FP8_IN_PROJ and act == torch.bfloat16 and ops.fp8_proj_supported(out[0], out[0].shape[1]):
             mf._cad_step_cache["w_in_fp8"] = ops.quant_weight_fp8(ps[0])  # from the fp32 master weight, once per step
 
@@ -231,10 +242,12 @@ class BiMambaMixerFn(torch.autograd.Function):
         _keep, seg_P = ops.scan_fwd_launch(lib, args, 2, stream, k, [st[2] for st in sets], dirs, split)
         y_f, y_r = outs
         out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
+        wT = cache.get("wT") if cache else None
         keep = [x2d, xz, w_in, w_out, ycat]
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt = sets[i]
             keep += [xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, states[i], ps[7 * i + 5]]
+        ctx.wT = wT  # (not saved tensors: plain per-step copies owned by the cache)
         ctx.save_for_backward(*keep, *seg_P)
         ctx.meta = (SB, Lq, split, [tuple(None if p is None else (p.dtype, p.shape) for p in ps[7 * i:7 * i + 7])
                                     for i in range(2)], W_in.dtype, W_out.dtype, tuple(fused_sp), k)
@@ -253,8 +266,9 @@ class BiMambaMixerFn(torch.autograd.Function):
         dirs = ((0, 1), (1, 0))
         dout2d = dout2d.contiguous()
         # tied out_proj: the gradient w.r.t. y_f and y_r is the same tensor, produced channel-major
+        wT = ctx.wT
         if ops.proj_supported(dout2d, Dm):
-            dy = ops.proj_wxT(w_out.t().contiguous(), dout2d).view(E, SB, Lq)
+            dy = ops.proj_wxT(wT["out"] if wT else w_out.t().contiguous(), dout2d).view(E, SB, Lq)
         else:
             dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)
         y_f, y_r = ycat[:E], ycat[E:]
@@ -310,14 +324,15 @@ class BiMambaMixerFn(torch.autograd.Function):
             L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
                     "cad_reduce_partials")
             if ops.proj_wx_supported(ddelta, E, T, M=R):
-                ops.proj_wx(w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+                ops.proj_wx(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
             else:
                 torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
             dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
             # d(xc) = du + W_x^T . d(dbc), in place (no copy of the 268 MB addend)
             if ops.proj_wx_supported(du, R + 2 * N, T):
-                ops.proj_wx(w_x.t().contiguous(), ddbc.view(R + 2 * N, T), out=du.view(E, T), acc=du.view(E, T))
+                ops.proj_wx(wT["x"][i] if wT else w_x.t().contiguous(), ddbc.view(R + 2 * N, T), out=du.view(E, T),
+                            acc=du.view(E, T))
             else:
                 du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))
             dxcs.append(du)
