@@ -105,16 +105,28 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
     for (int64_t b = b0; b < nblk; b += bstep, cur ^= 1) {
         if (b + bstep < nblk) gp_issue_block<KS>(X, a.ldx, (b + bstep) * C::NT, T, xb[cur ^ 1], wave, lane);
         const char* xt = xb[cur];
-#pragma unroll
-        for (int q = 0; q < C::NT / 16; ++q) {  // 16-token sub-blocks
-            // A fragments: token t = 16 q + jl, k = 32 ks + 8 g .. + 7  ->  logical piece 4 ks + g, swizzled with the token
-            u32x4 xf[KS];
+        // A fragments of sub-block q: token t = 16 q + jl, k = 32 ks + 8 g .. + 7  ->  logical piece 4 ks + g, swizzled with the token.
+        // Double buffered in registers where they fit (KS <= 8): the reads of sub-block q + 1 are issued before the MFMAs of
+        // sub-block q, so that the matrix cores do not idle for an LDS round trip four times per block.
+        constexpr int XFB = KS <= 8 ? 2 : 1;
+        u32x4 xfb[XFB][KS];
+        auto load_frags = [&](int q, u32x4* dst) {
             const int t = q * 16 + jl;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int s = ks * 4 + g;
                 const int ps = (s & ~C::SW) | ((s ^ t) & C::SW);
-                xf[ks] = *(const u32x4*)(xt + t * C::ROWB + ps * 16);
+                dst[ks] = *(const u32x4*)(xt + t * C::ROWB + ps * 16);
+            }
+        };
+        if constexpr (XFB == 2) load_frags(0, xfb[0]);
+#pragma unroll
+        for (int q = 0; q < C::NT / 16; ++q) {  // 16-token sub-blocks
+            u32x4* xf = xfb[XFB == 2 ? (q & 1) : 0];
+            if constexpr (XFB == 2) {
+                if (q + 1 < C::NT / 16) load_frags(q + 1, xfb[(q + 1) & 1]);
+            } else {
+                load_frags(q, xf);
             }
             f32x4 d[C::MB];
 #pragma unroll
@@ -140,23 +152,36 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
         // the next block has landed (this wave's share; the barrier below publishes everybody's).  Waited for BEFORE this
         // block's stores are issued, so that the wait never sits behind fresh write acknowledgements.
         gp_wait_dma();
-        // staging tile -> HBM: NT / 8 lanes cover the tokens of one channel row (16 bytes each)
+        // staging tile -> HBM: NT / 8 lanes cover the tokens of one channel row (16 bytes each).  All rows are read from the tile
+        // first and stored afterwards (one LDS round trip per block instead of one per row group); whole blocks of a fully
+        // populated, 16-byte aligned output take the straight-line path.
         const int64_t t0 = b * C::NT;
         constexpr int LPR = C::NT / 8, RPI = 64 / LPR;  // lanes per row, rows per instruction
+        u32x4 sv[C::MW / RPI];
 #pragma unroll
-        for (int r0 = 0; r0 < C::MW; r0 += RPI) {
-            const int r = r0 + lane / LPR, c8 = lane % LPR;
-            const u32x4 v = *(const u32x4*)(stage + r * C::SSTR + c8 * 16);
-            const int m = m_wave + r;
-            const int64_t t = t0 + c8 * 8;
-            if (m < M) {
-                bf16_t* dst = out + (int64_t)m * a.ldo + t;
-                if (t + 8 <= T && (((uintptr_t)dst) & 15) == 0) {
-                    *(u32x4*)dst = v;
-                } else {
+        for (int r0 = 0; r0 < C::MW; r0 += RPI)
+            sv[r0 / RPI] = *(const u32x4*)(stage + (r0 + lane / LPR) * C::SSTR + (lane % LPR) * 16);
+        const bool fast = t0 + C::NT <= T && m_wave + C::MW <= M && (a.ldo % 8) == 0 && (((uintptr_t)out) & 15) == 0;  // wave-uniform
+        if (fast) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (t + e < T) dst[e].v = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+            for (int r0 = 0; r0 < C::MW; r0 += RPI)
+                *(u32x4*)(out + (int64_t)(m_wave + r0 + lane / LPR) * a.ldo + t0 + (lane % LPR) * 8) = sv[r0 / RPI];
+        } else {
+#pragma unroll
+            for (int r0 = 0; r0 < C::MW; r0 += RPI) {
+                const int r = r0 + lane / LPR, c8 = lane % LPR;
+                const u32x4 v = sv[r0 / RPI];
+                const int m = m_wave + r;
+                const int64_t t = t0 + c8 * 8;
+                if (m < M) {
+                    bf16_t* dst = out + (int64_t)m * a.ldo + t;
+                    if (t + 8 <= T && (((uintptr_t)dst) & 15) == 0) {
+                        *(u32x4*)dst = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (t + e < T) dst[e].v = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+                    }
                 }
             }
         }

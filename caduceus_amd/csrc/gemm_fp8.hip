@@ -200,17 +200,23 @@ __global__ __launch_bounds__(64 * GF_WAVES, 2) void proj_wxT_fp8_kernel(cad_proj
         if (b + bstep < nblk) gf_issue_block<KS>(X, a.ldx, (b + bstep) * C::NT, T, xb[cur ^ 1], wave, lane);
         const char* xt = xb[cur];
         const int64_t t0 = b * C::NT;
-#pragma unroll
-        for (int q = 0; q < C::NT / 16; ++q) {
-            // A fragments: token t = 16 q + jl, k = 32 ks + 8 g .. + 7: byte offset 32 ks + 8 g = piece 2 ks + (g >> 1), half g & 1
-            u32x2 xf[KS];
+        // A fragments of sub-block q: token t = 16 q + jl, k = 32 ks + 8 g .. + 7: byte offset 32 ks + 8 g = piece 2 ks + (g >> 1),
+        // half g & 1; double buffered in registers (the reads of sub-block q + 1 run under the MFMAs of sub-block q)
+        u32x2 xfb[2][KS];
+        auto load_frags = [&](int q, u32x2* dst) {
             const int t = q * 16 + jl;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int s = ks * 2 + (g >> 1);
                 const int ps = (s & ~C::SW) | ((s ^ t) & C::SW);
-                xf[ks] = *(const u32x2*)(xt + t * C::ROWB + ps * 16 + (g & 1) * 8);
+                dst[ks] = *(const u32x2*)(xt + t * C::ROWB + ps * 16 + (g & 1) * 8);
             }
+        };
+        load_frags(0, xfb[0]);
+#pragma unroll
+        for (int q = 0; q < C::NT / 16; ++q) {
+            const u32x2* xf = xfb[q & 1];
+            if (q + 1 < C::NT / 16) load_frags(q + 1, xfb[(q + 1) & 1]);
             f32x4 d[C::MB];
 #pragma unroll
             for (int mb = 0; mb < C::MB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -238,20 +244,31 @@ __global__ __launch_bounds__(64 * GF_WAVES, 2) void proj_wxT_fp8_kernel(cad_proj
         cad_wave_sync();
         gf_wait_dma();
         constexpr int LPR = C::NT / 8, RPI = 64 / LPR;  // lanes per row, rows per instruction
+        u32x4 sv[C::MW / RPI];  // all rows read from the tile first, stored afterwards (see proj_wxT_kernel)
 #pragma unroll
-        for (int r0 = 0; r0 < C::MW; r0 += RPI) {
-            const int r = r0 + lane / LPR, c8 = lane % LPR;
-            const u32x4 v = *(const u32x4*)(stage + r * C::SSTR + c8 * 16);
-            const int m = m_wave + r;
-            const int64_t t = t0 + c8 * 8;
-            if (m < M) {
-                bf16_t* dst = out + (int64_t)m * a.ldo + t;
-                if (t + 8 <= T && (((uintptr_t)dst) & 15) == 0) {
-                    *(u32x4*)dst = v;
-                } else {
+        for (int r0 = 0; r0 < C::MW; r0 += RPI)
+            sv[r0 / RPI] = *(const u32x4*)(stage + (r0 + lane / LPR) * C::SSTR + (lane % LPR) * 16);
+        const bool fast = t0 + C::NT <= T && m_wave + C::MW <= M && (a.ldo % 8) == 0 && (((uintptr_t)out) & 15) == 0;  // wave-uniform
+        if (fast) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (t + e < T) dst[e].v = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+            for (int r0 = 0; r0 < C::MW; r0 += RPI)
+                *(u32x4*)(out + (int64_t)(m_wave + r0 + lane / LPR) * a.ldo + t0 + (lane % LPR) * 8) = sv[r0 / RPI];
+        } else {
+#pragma unroll
+            for (int r0 = 0; r0 < C::MW; r0 += RPI) {
+                const int r = r0 + lane / LPR, c8 = lane % LPR;
+                const u32x4 v = sv[r0 / RPI];
+                const int m = m_wave + r;
+                const int64_t t = t0 + c8 * 8;
+                if (m < M) {
+                    bf16_t* dst = out + (int64_t)m * a.ldo + t;
+                    if (t + 8 <= T && (((uintptr_t)dst) & 15) == 0) {
+                        *(u32x4*)dst = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (t + e < T) dst[e].v = (uint16_t)(v[e >> 1] >> (16 * (e & 1)));
+                    }
                 }
             }
         }
