@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-end evidence on ONE box: the GPU parity suite, smoke(), counter + trace profiles of the scans (-> profiles/r03_scan_pmc.json,
+# stamped with cad_version()), the whole-step kernel trace, and the default bench line.
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_final.log 2>&1; grep -n "passed\|failed" gpurun_out/pytest_gpu_final.log | tail -2
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+rm -rf gpurun_out/prof; timeout 900 bash tools/prof_scan.sh > gpurun_out/prof_scan.log 2>&1
+python tools/make_scan_pmc_json.py gpurun_out/prof gpurun_out/scan_pmc.json 2>&1 | tail -1 | cut -c1-600
+python tools/summarize_prof.py gpurun_out/prof > gpurun_out/prof_summary.txt 2>&1; grep -n "scan_bwd_kernel\|scan_fwd_kernel" gpurun_out/prof_summary.txt | head -4 | cut -c1-260
+timeout 600 bash tools/prof_step.sh 2>&1 | tail -1 | cut -c1-200
+python - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/prof_step/trace/**/*kernel_stats.csv", recursive=True)
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = [f"total kernel time per step: {tot / 3e6:.1f} ms (3 steps traced incl. warm-up)"]
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
+        out.append(f"{float(r['TotalDurationNs']) / 3e6:8.2f} ms/step {float(r['Percentage']):6.2f}% calls/step={int(r['Calls']) / 3:7.1f} avg_us={float(r['AverageNs']) / 1e3:9.1f}  {r['Name'][:150]}")
+    open("gpurun_out/step_trace_final.txt", "w").write("\n".join(out) + "\n")
+    print("\n".join(out[:14]))
+PY
+timeout 400 python bench.py > gpurun_out/bench_final.log 2>gpurun_out/bench_final.err; tail -1 gpurun_out/bench_final.log | cut -c1-400

@@ -28,7 +28,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.
         if grid and grid != two_set_threads:
             continue
         acc[kind][r["Counter_Name"]].append(float(r["Counter_Value"] or 0))
-res = {"source": "rocprofv3 --pmc passes of tools/prof_scan.sh over tools/scan_bench.py --only-scan (FETCH_SIZE, WRITE_SIZE and two SQ "
+res = {"source": "rocprofv3 --pmc passes of tools/prof_scan.sh over tools/layer_bench.py (one production mixer layer) (FETCH_SIZE, WRITE_SIZE and two SQ "
                  "groups, each in its own pass, no tracing combined); per-dispatch averages of the two-set production launches; "
                  "FETCH_SIZE x 2 (gfx950 correction), both size counters reported in KiB",
        "lib_version": _lib.version(),
