@@ -62,7 +62,7 @@ class ScanArgs(C.Structure):
     _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
                 ("delta_bias", _p), ("out", _p), ("chunk_state", _p), ("SB", _i64), ("L", _i64), ("split", _i64),
                 ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i), ("h0", _p), ("hT", _p),
-                ("sum_dt", _p), ("delta_is_dt", _i), ("bc_tiles", _p), ("map_only", _i)]
+                ("sum_dt", _p), ("delta_is_dt", _i), ("map_only", _i)]
 
 
 class ScanBwdArgs(C.Structure):
@@ -71,7 +71,7 @@ class ScanBwdArgs(C.Structure):
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
                 ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p), ("gate_fix_list", _p), ("gate_fix_count", _p),
-                ("gate_fix_dz", _p), ("delta_is_dt", _i), ("bc_tiles", _p), ("carry_only", _i)]
+                ("gate_fix_dz", _p), ("delta_is_dt", _i), ("carry_only", _i)]
 
 
 class MlmArgs(C.Structure):
@@ -83,11 +83,6 @@ class MlmArgs(C.Structure):
 class ProjArgs(C.Structure):
     _fields_ = [("W", _p), ("X", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
                 ("ldo", _i64), ("acc", _p), ("ldacc", _i64), ("bias", _p), ("act", _i)]
-
-
-class BcTilesArgs(C.Structure):
-    _fields_ = [("Bm", _p), ("Cm", _p), ("tiles", _p), ("SB", _i64), ("L", _i64), ("split", _i64), ("N", _i),
-                ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
 
 
 class QuantFp8Args(C.Structure):
@@ -128,8 +123,6 @@ SYMBOLS = {
     "cad_scan_bwd_partials": (_i, [_i]),
     "cad_scan_bwd_gate_fix": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_scan_gate_fix_entries": (_i64, [_i, _i64, _i64]),
-    "cad_scan_bc_tiles": (_i, [C.POINTER(BcTilesArgs), _p]),
-    "cad_scan_bc_tiles_floats": (_i64, [_i64, _i64, _i]),
     "cad_proj_wxT": (_i, [C.POINTER(ProjArgs), _p]),
     "cad_proj_supported": (_i, [_i]),
     "cad_proj_wx": (_i, [C.POINTER(ProjArgs), _p]),

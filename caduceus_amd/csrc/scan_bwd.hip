@@ -75,10 +75,7 @@ __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0
 // CO = carry-only instantiation (cad_scan_bwd_args.carry_only, pass 1 of an L-split backward): the reverse recurrence of the
 // state gradient alone -- exp, C * dy, one chain per item and state, the reverse wave scan -- and dh0 as its only output.  A
 // separate instantiation, so the full kernel carries none of its branches (measured: +5 % when they were run-time branches).
-// TL = tile-image instantiation (cad_scan_bwd_args.bc_tiles; bf16 production shapes only): the B / C tile pair of a pair-step comes
-// from the fp32 image of cad_scan_bc_tiles as eight 1 KB LDS-DMA copies, one per wave -- no staging registers, no conversion, the
-// same work on every wave.
-template <typename T, bool VEC, bool CO, bool TL>
+template <typename T, bool VEC, bool CO>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][wave][dB,dC][ACC_TILE] contributions
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
@@ -133,17 +130,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     StageRegs<T, SC_SV(SC_S)> st;
     StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
     ScVec<T, SC_S> u_raw, d_raw, g_raw, z_raw, o_raw, o2_raw;  // u_raw / d_raw stay in registers until the chunk's epilogue
-    // tile image: wave w copies KB w of the 8 KB (B, C) pair of (chunk cq, pair pq) into tile buffer b
-    static_assert(!TL || (VEC && sizeof(T) == 2 && SC_W == 8 && SC_S == 8), "tile image: bf16 production kernel");
-    const float* img = a.bc_tiles;
-    const uint32_t tile_lds = cad_uniform((int)(sc_lds_off(smem) + wave * 1024));
-    auto tile_dma = [&](int64_t cq, int pq, int b) {
-        sc_glds16(img + sc_img_pair(sb, cq, pq, nchunks, NP) + wave * 256 + lane * 4, tile_lds + b * (2 * SC_IMG_TILE * 4));
-    };
-    if constexpr (TL) {
-        tile_dma(nchunks - 1, 0, 0);
-        sc_wait_tile_dma(false);
-    } else {
+    {
         const int64_t base = (nchunks - 1) * SC_CHUNK;
         if constexpr (VEC) {
             sc_stage_seek<T, SC_S>(sctx, base, L, rev);
@@ -337,9 +324,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         for (int np = 0; np < NP; ++np, ++tix) {
             const int buf = tix & 1;
             const bool more = (np + 1 < NP) || (c > 0);
-            if constexpr (TL) {
-                if (more) tile_dma((np + 1 < NP) ? c : c - 1, (np + 1 < NP) ? np + 1 : 0, buf ^ 1);
-            } else if (more) {
+            if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
                 const int64_t nb = (np + 1 < NP) ? base : base - SC_CHUNK;
                 if constexpr (VEC) {
@@ -355,9 +340,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if constexpr (PREF) {
                 if (dma_now) prefetch_vectors(p0 - SC_CHUNK);
             }
-            // LDS tile: [lane][item][state] rows of ROW floats (staged tiles) or the image layout [piece][lane][2 items x 2 states]
-            const float* tB = TL ? smem + buf * (2 * SC_IMG_TILE) + lane * 4 : smem + buf * 2 * TILE + lane * ROW;
-            const float* tC = tB + (TL ? SC_IMG_TILE : TILE);
+            const float* tB = smem + buf * 2 * TILE + lane * ROW;
+            const float* tC = tB + TILE;
             float* aB = acc + (SC_SLAB_BUFS == 2 ? buf : 0) * ACC_BUF + wave * 2 * ACC_TILE + lane * 2;  // (i, s) at aB[i * ACC_ISTR + s]: 8-byte stride
             float* aC = aB + ACC_TILE;
             const int n0 = 2 * np;
@@ -372,7 +356,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 if (SC_WHATIF & 64)
                     Bw[i] = f2(__builtin_bit_cast(float, lane + i)), Cv[i] = f2(__builtin_bit_cast(float, lane - i));
                 else
-                    Bw[i] = ld2(tB + (TL ? (i >> 1) * 256 + (i & 1) * 2 : 2 * i)), Cv[i] = ld2(tC + (TL ? (i >> 1) * 256 + (i & 1) * 2 : 2 * i));
+                    Bw[i] = ld2(tB + 2 * i), Cv[i] = ld2(tC + 2 * i);
             }
             SC_TIME(2);  // staging issue + B/C tile reads
             if constexpr (CO) {
@@ -467,11 +451,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             }  // !CO
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
-            if constexpr (TL) {
-                if (more) sc_wait_tile_dma(dma_now);  // this wave's KB of the next tile pair has landed (the barrier publishes all eight)
-            } else {
-                if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
-            }
+            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
             SC_TIME(9);  // staging store (waits for the tile loads)
             if (!(SC_WHATIF & 2)) __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             SC_TIME(10);  // barrier wait
@@ -766,29 +746,16 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     const size_t slab_floats = a->carry_only ? 0 : (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF);
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + slab_floats) * sizeof(float) +
                          (pref ? PRE_BYTES : 0);
-#define SC_BWD_LAUNCH4(T, V, CO_, TL_)                                                         \
-    do {                                                                                       \
-        SC_BIG_LDS((scan_bwd_kernel<T, V, CO_, TL_>), shmem);                                  \
-        CAD_LAUNCH((scan_bwd_kernel<T, V, CO_, TL_>), grid, block, shmem, stream, ks);         \
+#define SC_BWD_LAUNCH(T, V)                                                                  \
+    do {                                                                                     \
+        if (a->carry_only) {                                                                 \
+            SC_BIG_LDS((scan_bwd_kernel<T, V, true>), shmem);                                \
+            CAD_LAUNCH((scan_bwd_kernel<T, V, true>), grid, block, shmem, stream, ks);       \
+        } else {                                                                             \
+            SC_BIG_LDS((scan_bwd_kernel<T, V, false>), shmem);                               \
+            CAD_LAUNCH((scan_bwd_kernel<T, V, false>), grid, block, shmem, stream, ks);      \
+        }                                                                                    \
     } while (0)
-#define SC_BWD_LAUNCH(T, V)                                                                    \
-    do {                                                                                       \
-        if (a->carry_only)                                                                     \
-            SC_BWD_LAUNCH4(T, V, true, false);                                                 \
-        else                                                                                   \
-            SC_BWD_LAUNCH4(T, V, false, false);                                                \
-    } while (0)
-    bool tiled = pref;  // tile-image instantiation: bf16 production shapes with an image for every set
-    for (int i = 0; i < nsets; ++i) tiled = tiled && sets[i].bc_tiles != nullptr && ((uintptr_t)sets[i].bc_tiles % 16) == 0;
-    if constexpr (SC_S == 8 && SC_W == 8) {  // (tuning builds with other chunk shapes have no tile-image instantiation)
-        if (tiled) {
-            if (a->carry_only)
-                SC_BWD_LAUNCH4(bf16_t, true, true, true);
-            else
-                SC_BWD_LAUNCH4(bf16_t, true, false, true);
-            return cad_after_launch();
-        }
-    }
     if (a->dtype == CAD_F32) {
         if (vec)
             SC_BWD_LAUNCH(float, true);
@@ -802,7 +769,6 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     } else {
         return CAD_ERR_UNSUPPORTED;
     }
-#undef SC_BWD_LAUNCH4
 #undef SC_BWD_LAUNCH
     return cad_after_launch();
 }

@@ -751,34 +751,6 @@ __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float*
     }
 }
 
-// ---- B/C tiles from the fp32 tile image (cad_scan_bc_tiles, scan_tiles.hip) ---------------------------------------------------
-// Image tile of one (row, 512-position chunk, state pair, tensor): [piece k = 0..3][lane j = 0..63][4 floats = items 2k, 2k + 1 x
-// states 0 / 1] = 1024 floats, B tile then C tile per pair.  It IS the LDS layout of the backward (chunk = 512 positions: lane j
-// reads piece k at k * 1 KB + 16 j: consecutive lanes, conflict-free ds_read_b128), so a tile pair is eight linear 1 KB LDS-DMA copies,
-// one per wave; the forward (1024-position chunks, 16 items per lane) gathers the pieces of image lanes 2 (j % 32), 2 (j % 32) + 1 of
-// image chunk 2 c + j / 32 into [piece q = 0..7][lane j][4 floats] with per-lane source addresses.
-#define SC_IMG_TILE 1024
-__device__ __forceinline__ int64_t sc_img_pair(int64_t sb, int64_t c, int np, int64_t NC, int NP) {
-    return (((sb * NC + c) * NP + np) * 2) * SC_IMG_TILE;  // float offset of the (B, C) tile pair
-}
-// wait until this wave's tile DMA has landed; `keep_dma`: the SC_NDMA item-vector DMAs issued BEHIND it stay in flight
-__device__ __forceinline__ void sc_wait_tile_dma(bool keep_dma) {
-#ifndef CAD_EMU
-    const uint32_t k = __builtin_amdgcn_readfirstlane(keep_dma ? 1u : 0u);
-    asm volatile(
-        "s_cmp_eq_u32 %0, 0\n\t"
-        "s_cbranch_scc1 .Lsc_twait0_%=\n\t"
-        "s_waitcnt vmcnt(6)\n\t"
-        "s_branch .Lsc_twaitd_%=\n"
-        ".Lsc_twait0_%=:\n\t"
-        "s_waitcnt vmcnt(0)\n"
-        ".Lsc_twaitd_%=:"
-        :
-        : "s"(k)
-        : "memory", "scc");
-#endif
-}
-
 // more than 64 KB of dynamic LDS has to be requested per kernel; remembered per call site and per device (see gemm.hip)
 #if defined(CAD_EMU)
 #define SC_BIG_LDS(kern, bytes) (void)0

@@ -33,16 +33,10 @@ struct ScanFwdSets {
 
 // MO = map-only instantiation (cad_scan_args.map_only, pass 1 of an L-split scan): recurrence and wave scan only -- hT and
 // sum_dt are the outputs; no C tile reads, no output phase, no gate, no stores of `out` / chunk states.
-// TL = tile-image instantiation (cad_scan_args.bc_tiles; bf16 production shapes only): the (B, C) tile pair of a pair-step is gathered
-// from the fp32 image of cad_scan_bc_tiles by sixteen 1 KB LDS-DMA copies (two per wave; a forward lane's 16 items are the two image
-// lanes 2 (j % 32), 2 (j % 32) + 1 of image chunk 2 c + j / 32) -- no staging registers, no conversion, the same work on every wave.
-template <typename T, bool VEC, bool MO, bool TL>
+template <typename T, bool VEC, bool MO>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [SC_RING_FWD slots][B,C][SC_TILE]
-    // staged tiles: [lane][item][state] rows of ROW floats; image tiles: [piece q = 0..7][lane][2 items x 2 states]
-    constexpr int TILE = TL ? 2 * SC_IMG_TILE : SC_TILE(SC_S), ROW = SC_ROW(SC_S);
-    static_assert(!TL || (VEC && sizeof(T) == 2 && SC_W == 8 && SC_S == 16 && 2 * SC_IMG_TILE <= SC_TILE(SC_S)),
-                  "tile image: bf16 production kernel, tiles fit the staged ring");
+    constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     constexpr int RING = SC_RING_FWD, AHEAD = RING / 2;
     static_assert(RING >= 2 && (RING & (RING - 1)) == 0, "ring of 2^k tiles");
     constexpr int SLOTS = SC_CHUNK / SC_STATE_STEP;  // saved-state slots per forward chunk (1 or 2)
@@ -104,9 +98,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     if constexpr (VEC) sc_stage_seek<T, SC_S>(sctx, 0, L, rev);
     ScVec<T, SC_S> u_raw, d_raw, z_raw;
     const int ntiles = (int)nchunks * NP;
-    int s_np = 0;        // staging cursor: (chunk base, pair) of the next tile to stage, and its running index
+    int s_np = 0;        // staging cursor: (chunk base, pair) of the next tile to stage
     int64_t s_base = 0;
-    int s_tix = 0;
     if constexpr (PREF) {
         prefetch_vectors(0);
     } else {
@@ -114,34 +107,15 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
         sc_load_raw<T, SC_S, VEC>(d_row, (int64_t)lane * SC_S, L, rev, d_raw);
     }
     // stage the tile of the cursor / move the cursor on (wave-uniform)
-    // tile image: this lane's source of piece q (image chunk 2 c + j / 32 clamped to the last chunk of the row -- the positions of a
-    // missing half chunk are masked by dt = 0 --, image lane 2 (j % 32) + q / 4, piece q % 4), relative to the (chunk 0, pair 0) pair
-    const float* img = a.bc_tiles;
-    const int64_t n_img = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
-    const uint32_t ring_lds = cad_uniform((int)sc_lds_off(smem));
-    auto tile_dma = [&](int64_t cbase /* logical chunk start */, int pq, int slot) {
-        int64_t ci = cbase / SC_STATE_STEP + (lane >> 5);
-        ci = ci < n_img ? ci : n_img - 1;
-        const float* src = img + sc_img_pair(sb, ci, pq, n_img, NP) + (2 * (lane & 31)) * 4;
-#pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-            const int d = wave + 8 * rep, ten = d >> 3, q = d & 7;  // wave-uniform
-            sc_glds16(src + ten * SC_IMG_TILE + (q & 3) * 256 + (q >> 2) * 4,
-                      ring_lds + (uint32_t)((slot * 2 * TILE + ten * TILE + q * 256) * 4));
-        }
-    };
 #define SC_FWD_STAGE()                                                                 \
     do {                                                                               \
-        if constexpr (TL)                                                              \
-            tile_dma(s_base, s_np, (int)(s_tix & (RING - 1)));                         \
-        else if constexpr (VEC)                                                        \
+        if constexpr (VEC)                                                             \
             sc_stage_issue<T, SC_S>(st, sctx, 2 * s_np, N);                            \
         else                                                                           \
             sc_stage_load<T, SC_S, false>(st, sctx, 2 * s_np, N, s_base, L, rev);        \
     } while (0)
 #define SC_FWD_ADVANCE()                                                               \
     do {                                                                               \
-        ++s_tix;                                                                       \
         if (++s_np == NP) {                                                            \
             s_np = 0, s_base += SC_CHUNK;                                              \
             if constexpr (VEC) sc_stage_seek<T, SC_S>(sctx, s_base, L, rev);           \
@@ -149,10 +123,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     } while (0)
     for (int g = 0; g < AHEAD; ++g) {
         SC_FWD_STAGE();
-        if constexpr (!TL) sc_stage_store<T, SC_S, VEC>(st, smem + g * 2 * TILE, rev);
+        sc_stage_store<T, SC_S, VEC>(st, smem + g * 2 * TILE, rev);
         SC_FWD_ADVANCE();
     }
-    if constexpr (TL) sc_wait_tile_dma(false);
     __syncthreads();
 
     f32x2 carry = f2(0.f);  // lane np holds the running state of pair np at the current chunk start
@@ -231,7 +204,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             if constexpr (PREF) {
                 if (dma_now) prefetch_vectors(c + 1);
             }
-            const float* tB = smem + buf * 2 * TILE + (TL ? lane * 4 : lane * ROW);
+            const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
             const f32x2 A2 = readlane2(Areg, np);
             // (i) serial scan over the lane's items
@@ -240,7 +213,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const f32x2 av = (SC_WHATIF & 128) ? splat_lo(dd[i]) * A2 : exp2_2(splat_lo(dd[i]) * A2);
-                const f32x2 bv = splat_hi(dd[i]) * ((SC_WHATIF & 64) ? f2(__builtin_bit_cast(float, lane + i)) : ld2(tB + (TL ? (i >> 1) * 256 + (i & 1) * 2 : 2 * i)));
+                const f32x2 bv = splat_hi(dd[i]) * ((SC_WHATIF & 64) ? f2(__builtin_bit_cast(float, lane + i)) : ld2(tB + 2 * i));
                 acc_h = av * acc_h + bv;
                 acc_a = acc_a * av;
                 ha[i] = acc_a;
@@ -271,17 +244,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
                 const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
-                const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]} : *(const f32x4*)(tC + (TL ? (i >> 1) * 256 : 2 * i));
+                const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]} : *(const f32x4*)(tC + 2 * i);
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
             }
             }
             SC_TIME(4);  // output phase (C tile reads)
             if (more) {
-                if constexpr (TL)
-                    sc_wait_tile_dma(dma_now);  // this wave's two KB of the tile pair have landed (the barrier publishes all sixteen)
-                else
-                    sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev, dma_now);
+                sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev, dma_now);
                 SC_FWD_ADVANCE();
             }
             SC_TIME(5);  // staging store
@@ -356,29 +326,16 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const size_t shmem = (size_t)SC_RING_FWD * 2 * SC_TILE(SC_S) * sizeof(float) +
                          ((SC_FWD_DMA && vec && a->dtype == CAD_BF16 && SC_S == 16) ? PRE_BYTES : 0);
-#define SC_FWD_LAUNCH4(T, V, MO_, TL_)                                                         \
-    do {                                                                                       \
-        SC_BIG_LDS((scan_fwd_kernel<T, V, MO_, TL_>), shmem);                                  \
-        CAD_LAUNCH((scan_fwd_kernel<T, V, MO_, TL_>), grid, block, shmem, stream, ks);         \
+#define SC_FWD_LAUNCH(T, V)                                                                  \
+    do {                                                                                     \
+        if (a->map_only) {                                                                   \
+            SC_BIG_LDS((scan_fwd_kernel<T, V, true>), shmem);                                \
+            CAD_LAUNCH((scan_fwd_kernel<T, V, true>), grid, block, shmem, stream, ks);       \
+        } else {                                                                             \
+            SC_BIG_LDS((scan_fwd_kernel<T, V, false>), shmem);                               \
+            CAD_LAUNCH((scan_fwd_kernel<T, V, false>), grid, block, shmem, stream, ks);      \
+        }                                                                                    \
     } while (0)
-#define SC_FWD_LAUNCH(T, V)                                                                    \
-    do {                                                                                       \
-        if (a->map_only)                                                                       \
-            SC_FWD_LAUNCH4(T, V, true, false);                                                 \
-        else                                                                                   \
-            SC_FWD_LAUNCH4(T, V, false, false);                                                \
-    } while (0)
-    bool tiled = SC_FWD_DMA && vec && a->dtype == CAD_BF16 && SC_S == 16;  // tile-image instantiation: an image for every set
-    for (int i = 0; i < nsets; ++i) tiled = tiled && sets[i].bc_tiles != nullptr && ((uintptr_t)sets[i].bc_tiles % 16) == 0;
-    if constexpr (SC_S == 16 && SC_W == 8) {  // (tuning builds with other chunk shapes have no tile-image instantiation)
-        if (tiled) {
-            if (a->map_only)
-                SC_FWD_LAUNCH4(bf16_t, true, true, true);
-            else
-                SC_FWD_LAUNCH4(bf16_t, true, false, true);
-            return cad_after_launch();
-        }
-    }
     if (a->dtype == CAD_F32) {
         if (vec)
             SC_FWD_LAUNCH(float, true);
@@ -392,7 +349,6 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
     } else {
         return CAD_ERR_UNSUPPORTED;
     }
-#undef SC_FWD_LAUNCH4
 #undef SC_FWD_LAUNCH
     return cad_after_launch();
 }

@@ -225,7 +225,7 @@ class BiMambaMixerFn(torch.autograd.Function):
         # launch would otherwise leave CUs idle (Caduceus-Ph at batch 1)
         k = ops.lsplit_factor(E, SB, Lq, 2)
         args = (L.ScanArgs * 2)()
-        outs, states, tile_imgs = [], [], []
+        outs, states = [], []
         ycat = torch.empty((2 * E, SB, Lq), dtype=act, device=x2d.device)  # [y_f ; y_r]: one out_proj GEMM with K = 2E
         for i, (xc, delta, A, dbc, Df, bfz, *_rest) in enumerate(sets):
             N, R = A.shape[1], dbc.shape[0] - 2 * A.shape[1]
@@ -237,10 +237,6 @@ class BiMambaMixerFn(torch.autograd.Function):
                                  L.ptr(out), L.ptr(state), SB * k, Lq // k, split * k, E, N, dirs[i][0], dirs[i][1],
                                  L.dtype_code(act))
             args[i].delta_is_dt = int(fused_sp[i])
-            # fp32 tile image of B / C in the scans' LDS layout: written once per layer, fetched by LDS-DMA in both kernels
-            tiles = ops.scan_bc_tiles(Bm, Cm, SB * k, Lq // k, split * k, dirs[i][0], dirs[i][1]) if ops.bc_tiles_wanted(xc) else None
-            args[i].bc_tiles = L.ptr(tiles)
-            tile_imgs.append(tiles)
             outs.append(out)
             states.append(state)
         _keep, seg_P = ops.scan_fwd_launch(lib, args, 2, stream, k, [st[2] for st in sets], dirs, split)
@@ -252,7 +248,6 @@ class BiMambaMixerFn(torch.autograd.Function):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt = sets[i]
             keep += [xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, states[i], ps[7 * i + 5]]
         ctx.wT = wT  # (not saved tensors: plain per-step copies owned by the cache)
-        ctx.tile_imgs = tile_imgs  # (derived from dbc, which IS saved)
         ctx.save_for_backward(*keep, *seg_P)
         ctx.meta = (SB, Lq, split, [tuple(None if p is None else (p.dtype, p.shape) for p in ps[7 * i:7 * i + 7])
                                     for i in range(2)], W_in.dtype, W_out.dtype, tuple(fused_sp), k)
@@ -312,7 +307,6 @@ class BiMambaMixerFn(torch.autograd.Function):
                                     L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None, L.ptr(fix_list[i]),
                                     L.ptr(fix_cnt[i]), L.ptr(dxz[E:]) if (_SHARED_GATE or i == 0) else L.ptr(dz))
             args[i].delta_is_dt = int(fused_sp[i])
-            args[i].bc_tiles = L.ptr(ctx.tile_imgs[i])
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
         _keep = ops.scan_bwd_launch(lib, args, 2, stream, k, seg_P, dirs, split)
         L.check(lib.cad_scan_bwd_gate_fix(args, 2, stream), "cad_scan_bwd_gate_fix")  # no-op unless some z == 0 exactly

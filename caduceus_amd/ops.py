@@ -266,27 +266,6 @@ def scan_bwd_launch(lib, args, nsets: int, stream, k: int, Ps, dirs, split: int)
     return keep
 
 
-# B/C tile image: built once per layer from the x_proj output, read by both scan kernels through LDS-DMA (csrc/scan_tiles.hip).
-# CADUCEUS_AMD_BC_TILES=0 keeps the staged tiles (A/B switch); only the bf16 production shapes have tile-image kernels.
-_BC_TILES = os.environ.get("CADUCEUS_AMD_BC_TILES", "1") != "0"
-
-
-def bc_tiles_wanted(u: torch.Tensor) -> bool:
-    return _BC_TILES and u.dtype == torch.bfloat16 and u.shape[-1] % 16 == 0
-
-
-def scan_bc_tiles(Bm: torch.Tensor, Cm: torch.Tensor, SB: int, Lq: int, split: int, rev_lo: int, rev_hi: int) -> torch.Tensor:
-    """fp32 tile image of Bm / Cm ((N, SB, L) views of contiguous storage; SB / Lq may describe the k-way reshaped rows of an
-    L-split launch) for cad_scan_args.bc_tiles / cad_scan_bwd_args.bc_tiles."""
-    lib = L.get_lib()
-    N = Bm.shape[0]
-    tiles = torch.empty((lib.cad_scan_bc_tiles_floats(SB, Lq, N),), dtype=torch.float32, device=Bm.device)
-    stream = L.stream_and_check(Bm, Cm, tiles)
-    a = L.BcTilesArgs(L.ptr(Bm), L.ptr(Cm), L.ptr(tiles), SB, Lq, split, N, rev_lo, rev_hi, L.dtype_code(Bm.dtype))
-    L.check(lib.cad_scan_bc_tiles(C.byref(a), stream), "cad_scan_bc_tiles")
-    return tiles
-
-
 def gate_fix_buffers(lib, u, N):
     """Worklist (int64 slots) + zeroed counter (int32) for the exact gate gradient at z == 0 (cad_scan_bwd_gate_fix)."""
     E, SB, Lq = u.shape
@@ -306,7 +285,7 @@ class _ScanMulti(torch.autograd.Function):
         z = None if z is None else z.contiguous()
         sets, args = [], (L.ScanArgs * nsets)()
         need_grad = any(ctx.needs_input_grad)
-        outs, tile_imgs = [], []
+        outs = []
         for i in range(nsets):
             u, delta, A, Bm, Cm, D, bias = tensors[7 * i:7 * i + 7]
             u, delta, Bm, Cm = u.contiguous(), delta.contiguous(), Bm.contiguous(), Cm.contiguous()
@@ -325,14 +304,10 @@ class _ScanMulti(torch.autograd.Function):
             args[i] = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
                                  L.ptr(out), L.ptr(state), SB * k, Lq // k, split * k, E, N, rl, rh, L.dtype_code(u.dtype))
             args[i].delta_is_dt = int(bool(delta_is_dt))
-            tiles = scan_bc_tiles(Bm, Cm, SB * k, Lq // k, split * k, rl, rh) if bc_tiles_wanted(u) else None
-            args[i].bc_tiles = L.ptr(tiles)
             sets.append((u, delta, Af, Bm, Cm, Df, bf, state, out))
             outs.append(out)
-            tile_imgs.append(tiles)
         _keep, Ps = scan_fwd_launch(lib, args, nsets, stream, k, [s_[2] for s_ in sets], dirs, split)
         flat = [t for s_ in sets for t in s_]
-        ctx.tile_imgs = tile_imgs if need_grad else None  # (derived from Bm / Cm: kept for the backward, not saved tensors)
         ctx.save_for_backward(z, *flat, *Ps)
         ctx.meta = (split, dirs, nsets, [(t[2].dtype, t[5].dtype, t[6].dtype) for t in
                                          [tensors[7 * i:7 * i + 7] for i in range(nsets)]], bool(delta_is_dt), k)
@@ -365,7 +340,6 @@ class _ScanMulti(torch.autograd.Function):
                                     split * k, E, N, rl, rh, L.dtype_code(u.dtype), npart, None, None, None, L.ptr(fix_list),
                                     L.ptr(fix_cnt), L.ptr(dz))
             args[i].delta_is_dt = int(delta_is_dt)
-            args[i].bc_tiles = L.ptr(ctx.tile_imgs[i]) if ctx.tile_imgs else None
             keep.append((dout, dBC, fix_list, fix_cnt))
             res.append([du, ddelta, dA, dBC, dD, dbias, dz])
         keep.append(scan_bwd_launch(lib, args, nsets, stream, k, Ps, dirs, split))

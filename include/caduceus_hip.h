@@ -199,9 +199,6 @@ typedef struct {
     float* sum_dt;
     int delta_is_dt;   /* 1: `delta` already holds dt = softplus(delta_raw + delta_bias) (written by cad_proj_wx with
                         * act = CAD_ACT_SOFTPLUS_BIAS); delta_bias is ignored */
-    const float* bc_tiles; /* optional: the fp32 tile image of Bm / Cm written by cad_scan_bc_tiles for exactly this (SB, L, split,
-                            * rev_lo, rev_hi, N).  The bf16 production kernels then fetch their B / C tiles from it by LDS-DMA in the
-                            * consumers' layout (no conversion, no staging through registers); ignored by the other instantiations */
     int map_only;      /* 1: only the row's affine state map is wanted -- hT (from h0, default 0) and sum_dt are written, `out`
                         * and chunk_state are not touched (may be NULL), C / D / z are not read.  Pass 1 of an L-split scan:
                         * the segments of a row are presented as rows (E, SB * k, L / k) of the same buffers. */
@@ -210,21 +207,6 @@ int cad_scan_fwd(const cad_scan_args* a, void* stream);
 /* Same, for nsets (1 or 2) independent parameter sets of identical shape in ONE launch -- the mamba_fwd and mamba_rev
  * scans of a BiMamba layer (modeling_caduceus.py:128-130) -- so that a CU holds two waves per SIMD even at batch 1. */
 int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream);
-/* fp32 tile image of B and C for the scans: for every row, 512-position chunk c, state pair np and tensor (B, C) one 4 KB tile
- * [piece k = 0..3][lane j = 0..63][items 2k, 2k+1 of lane j x states 2np, 2np+1] in the row's LOGICAL order (position
- * c * 512 + 8 j + i), zero beyond L / N -- the layout the scan kernels read from LDS, so that a tile travels global -> LDS as
- * eight 1 KB LDS-DMA copies.  tiles: cad_scan_bc_tiles_floats(SB, L, N) floats. */
-typedef struct {
-    const void* Bm;
-    const void* Cm;
-    float* tiles;
-    int64_t SB, L, split;
-    int N;
-    int rev_lo, rev_hi;
-    int dtype;
-} cad_bc_tiles_args;
-int cad_scan_bc_tiles(const cad_bc_tiles_args* a, void* stream);
-int64_t cad_scan_bc_tiles_floats(int64_t SB, int64_t L, int N);
 int64_t cad_scan_chunk_len(void);
 int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
 /* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E) are ACCUMULATED with a few fp32
@@ -276,7 +258,6 @@ typedef struct {
     void* gate_fix_dz;
     int delta_is_dt;   /* as in cad_scan_args; ddelta / ddelta_bias are still the gradients w.r.t. delta_raw / the bias:
                         * d(dt) * sigmoid(delta_raw + bias) = d(dt) * (1 - exp(-dt)) */
-    const float* bc_tiles; /* as in cad_scan_args */
     int carry_only;    /* 1: only dh0 (from dhT, default 0) is wanted -- the reverse recurrence of the state gradient alone
                         * (exp, C * dy, one chain per item and state); no other output is written, B / chunk_state / out are
                         * not read (du, ddelta, dA, dB, dC, dD, ddelta_bias, chunk_state may be NULL).  Pass 1 of an L-split

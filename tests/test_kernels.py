@@ -470,41 +470,3 @@ def test_scan_lsplit_two_pass_matches_unsplit_and_oracle(backend, monkeypatch, d
     ref = _rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, A, B_, C_, D, z_, b), [u, d, B, C, z], split, 0, 1)
     otol = FP32 if dtype == torch.float32 else BF16
     torch.testing.assert_close(b1.float().cpu(), ref.detach(), **otol)
-
-
-@pytest.mark.parametrize("case", [(8, 2, 3072, 16), (8, 2, 1536, 16), (5, 2, 1040, 5), (16, 3, 4096 + 512, 8)])
-def test_scan_bc_tile_image_is_bit_identical_to_staged_tiles(backend, monkeypatch, case):
-    """bf16 production kernels with the fp32 B / C tile image (cad_scan_bc_tiles + LDS-DMA in the consumers' layout) against the
-    same kernels staging their tiles through registers: the tiles hold the same fp32 values in another arrangement, so outputs
-    and every gradient must be BIT-identical -- both parameter sets of a layer, opposite directions, whole and half forward
-    chunks, a tail chunk, an odd number of states; and both against the oracle."""
-    name, dev = backend
-    E, SB, L, N = case
-    dtype, split = torch.bfloat16, 1
-    order = ("u", "delta", "A", "B", "C", "D", "bias")
-    act = {"u", "delta", "B", "C"}
-    t1, t2 = _scan_inputs(E, SB, L, N, 41, dev, dtype), _scan_inputs(E, SB, L, N, 42, dev, dtype)
-    dirs = [(0, 1), (1, 0)]
-
-    def run(tiles):
-        monkeypatch.setattr(ops, "_BC_TILES", tiles)
-        sets = [[leaf(t[n], dev, dtype if n in act else torch.float32) for n in order] for t in (t1, t2)]
-        z = leaf(t1["z"], dev, dtype)
-        o1, o2 = ops.selective_scan_multi([tuple(x) for x in sets], z, split, dirs)
-        ((o1.float() * t1["w"].to(dev)).sum() + (o2.float() * t2["w"].to(dev)).sum()).backward()
-        return (o1, o2), sets, z
-
-    (a1, a2), sa, za = run(False)
-    (b1, b2), sb_, zb = run(True)
-    assert torch.equal(a1, b1) and torch.equal(a2, b2)
-    assert torch.equal(za.grad, zb.grad)
-    for i in range(2):
-        for n, x, y in zip(order, sb_[i], sa[i]):
-            if n in ("A", "D", "bias"):  # a few fp32 atomics per channel: last-bit run-to-run noise
-                torch.testing.assert_close(x.grad, y.grad, rtol=1e-5, atol=1e-6 * max(1.0, float(y.grad.abs().max())))
-            else:
-                assert torch.equal(x.grad, y.grad), (i, n)
-    ref_ins = [leaf(t1[n], "cpu") for n in ("u", "delta", "A", "B", "C", "D", "z", "bias")]
-    u, d, A, B, C, D, z, b = ref_ins
-    ref = _rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, A, B_, C_, D, z_, b), [u, d, B, C, z], split, 0, 1)
-    torch.testing.assert_close(b1.float().cpu(), ref.detach(), **BF16)
