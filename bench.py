@@ -109,6 +109,11 @@ def cpu_baseline(scan_L=131072):
                                 "bwd_GBps": (7 * E + 4 * N) * 4 * scan_L / tb / 1e9}}
 
 
+# instruction price of one (channel, position, state pair) element on one SIMD, ns (DESIGN.md section 3 "Floors": the per-pair-step
+# instruction mix of each kernel priced with profiles/r01_ubench_gfx950.log; 0.5 us per 512-position backward pair-step and wave)
+INSTR_PRICE_NS = {"scan_fwd": 0.477, "scan_bwd": 0.977}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,7 +265,11 @@ def main():
                         "avg_launch_ms": kinds[dom]["avg_ms"], "launches": kinds[dom]["launches"],
                         "launches_per_layer_op": kinds[dom]["launches_per_op"],
                         "algorithmic_bytes_per_launch": kinds[dom]["algorithmic_bytes_per_launch"],
+                        # second ceiling: the kernels' instruction mix priced with this chip's micro-benchmark
+                        # (DESIGN.md section 3 "Floors"): ns per (channel, position, state PAIR) and SIMD, 1024 SIMDs
                         "all": {k: {"avg_ms": v["avg_ms"], "achieved_GBps": v["achieved_GBps"],
+                                    "hbm_bound_ms": alg[k] / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                    "instruction_price_ms": E * inv_tokens * ((N + 1) // 2) * INSTR_PRICE_NS[k] / 1024 * 1e-6,
                                     "share_of_step": v["total_ms"] / (elapsed * 1e3)} for k, v in kinds.items()},
                         "other_kernels_ms_per_step": {k: prof[k][0] / args.steps for k in prof
                                                       if k not in kinds and prof[k][1]}}
