@@ -703,41 +703,6 @@ __global__ void reduce_partials_kernel(const T* src, int nparts, int64_t n, T* d
     }
 }
 
-// bf16 fast path: 8 elements (one 16-byte load) per thread and slot, the slots walked in batches of eight independent loads; the
-// sum runs over the slots in ascending order as above (same bits), the pass is a pure stream of n_partials * n * 2 bytes
-__global__ __launch_bounds__(256) void reduce_partials_bf16x8_kernel(const bf16_t* src, int nparts, int64_t n, bf16_t* dst) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const bf16_t* p = src + i;
-        int k = 0;
-        for (; k + 8 <= nparts; k += 8) {
-            u32x4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = *(const u32x4*)(p + (int64_t)(k + q) * n);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    s[2 * w] += cad_bits2f(v[q][w] << 16);
-                    s[2 * w + 1] += cad_bits2f(v[q][w] & 0xffff0000u);
-                }
-        }
-        for (; k < nparts; ++k) {
-            const u32x4 v = *(const u32x4*)(p + (int64_t)k * n);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                s[2 * w] += cad_bits2f(v[w] << 16);
-                s[2 * w + 1] += cad_bits2f(v[w] & 0xffff0000u);
-            }
-        }
-        u32x4 o;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) o[w] = cad_pack_bf16x2(s[2 * w], s[2 * w + 1]);
-        *(u32x4*)(dst + i) = o;
-    }
-}
-
 }  // namespace
 
 SC_TIME_EXPORT(cad_debug_timing_bwd)
@@ -838,13 +803,6 @@ extern "C" int cad_reduce_partials(const void* src, int n_partials, int64_t n, v
     int64_t nb = (n / 4 + 255) / 256 + 1;
     if (nb > 16384) nb = 16384;
     dim3 grid((unsigned)nb), block(256);
-    if (dst_dtype == CAD_BF16 && vec && (n % 8) == 0) {
-        int64_t nb8 = (n / 8 + 255) / 256;
-        if (nb8 > 16384) nb8 = 16384;
-        CAD_LAUNCH(reduce_partials_bf16x8_kernel, dim3((unsigned)nb8), block, 0, stream, (const bf16_t*)src, n_partials, n,
-                   (bf16_t*)dst);
-        return cad_after_launch();
-    }
     if (dst_dtype == CAD_F32)
         CAD_LAUNCH((reduce_partials_kernel<float>), grid, block, 0, stream, (const float*)src, n_partials, n, (float*)dst, vec);
     else if (dst_dtype == CAD_BF16)
