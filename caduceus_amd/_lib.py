@@ -82,7 +82,8 @@ class MlmArgs(C.Structure):
 
 class ProjArgs(C.Structure):
     _fields_ = [("W", _p), ("X", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
-                ("ldo", _i64), ("acc", _p), ("ldacc", _i64), ("bias", _p), ("act", _i)]
+                ("ldo", _i64), ("acc", _p), ("ldacc", _i64), ("bias", _p), ("act", _i), ("wg_y", _p), ("ld_wg_y", _i64),
+                ("wg_partials", _p)]
 
 
 class QuantFp8Args(C.Structure):
@@ -128,6 +129,9 @@ SYMBOLS = {
     "cad_proj_wx": (_i, [C.POINTER(ProjArgs), _p]),
     "cad_proj_wx_supported": (_i, [_i, _i64]),
     "cad_proj_wx_thin_supported": (_i, [_i, _i, _i64]),
+    "cad_proj_wx_wgrad": (_i, [C.POINTER(ProjArgs), _p]),
+    "cad_proj_wx_wgrad_supported": (_i, [_i, _i, _i64]),
+    "cad_proj_wx_wgrad_partials": (_i, [_i64]),
     "cad_quant_rows_fp8": (_i, [C.POINTER(QuantFp8Args), _p]),
     "cad_proj_wxT_fp8": (_i, [C.POINTER(ProjFp8Args), _p]),
     "cad_proj_fp8_supported": (_i, [_i]),

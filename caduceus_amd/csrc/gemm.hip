@@ -458,6 +458,160 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
     }
 }
 
+
+// ---- cad_proj_wx_wgrad: the thin-M / deep-K product AND the weight gradient of the same operand from ONE pass over X -----------
+// d(dt_lr) (M = dt_rank rows) = W_dt^T . d(delta)  and  dW_dt (K = d_inner, M) = d(delta) . dt_lr^T  both stream the (K, T) tensor
+// d(delta); the second used to be a K-split hipBLASLt bmm + sum that read the 268 MB again.  Same skeleton as proj_wx_thin_kernel
+// (ring of four [64 rows][128 tokens] LDS tiles filled by LDS-DMA, counted waits); on top of it, per (block, chunk) every wave
+// runs two more MFMAs with the ROLES of the tile swapped: A = 16 channel rows of the tile x 32 tokens (token-contiguous rows are
+// A fragments as they lie: plain ds_read_b128), B = the matching 32 tokens of the M rows of Y (a [M][128] tile per block, double
+// buffered, XOR-swizzled through the DMA source addresses), accumulated in registers over ALL blocks of the workgroup -- NCH x MB
+// accumulator tiles per wave (the chunk loop is unrolled, so the tiles are addressed statically).  Wave w owns channel block w & 3
+// of every chunk and the token half w >> 2; the halves are summed through LDS at the end and the workgroup writes its (K, M) fp32
+// partial slot; the caller sums the <= 256 slots (fixed order).
+template <int MB, int NCH>
+__global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(cad_proj_args a) {
+    typedef GtCfg C;
+    CAD_DYN_SMEM(char, smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const int g = lane >> 4, jl = lane & 15;
+    const bf16_t* W = (const bf16_t*)a.W;
+    const bf16_t* X = (const bf16_t*)a.X;
+    const bf16_t* Y = (const bf16_t*)a.wg_y;
+    bf16_t* out = (bf16_t*)a.out;
+    const int64_t T = a.T;
+    const int M = a.M;
+    constexpr int K = NCH * C::KC;
+    constexpr int YBUF = MB * 16 * C::XROW;           // bytes per Y tile: [MB * 16 rows][128 tokens]
+    const int64_t nblk = T / C::NT;                   // (T % 128 == 0: no tail block, every staged token is a real token)
+    const int64_t b0 = blockIdx.x, bstep = gridDim.x;
+    const int64_t nmine = (nblk - b0 + bstep - 1) / bstep;  // >= 1: the grid never exceeds the number of blocks
+    const int64_t total = nmine * NCH;
+    char* wl = smem + C::RING * C::XBUF;
+    constexpr int WSTR = K * 2 + 16;
+    char* yt = wl + MB * 16 * WSTR;
+    auto issue = [&](int64_t it) {
+        const int64_t blk = b0 + (it / NCH) * bstep;
+        gt_issue_chunk(X, a.ldx, (int)(it % NCH) * C::KC, blk * C::NT, T, smem + (int)(it % C::RING) * C::XBUF, wave, lane);
+    };
+    // Y tile of block number bi (of this workgroup): MB * 4 DMA instructions of four rows each, one per wave 0 .. MB * 4 - 1;
+    // physical 16-byte piece pp of row r holds logical piece pp ^ (r & 15): the 16 rows a B-fragment read touches hit 16 distinct
+    // pieces = all 64 banks
+    auto issue_y = [&](int64_t bi) {
+        if (wave < MB * 4) {
+            const int row = wave * 4 + (lane >> 4), pp = lane & 15;
+            const int lp = pp ^ (row & 15);
+            const int64_t blk = b0 + bi * bstep;
+            const int rr = row < M ? row : M - 1;  // rows >= M: valid data, their columns of the result are never stored
+            cad_glds16(Y + (int64_t)rr * a.ld_wg_y + blk * C::NT + lp * 8,
+                       cad_uniform((int)(cad_lds_off(yt) + (int)(bi & 1) * YBUF + wave * 1024)));
+        }
+    };
+    issue_y(0);  // BEFORE the chunks: vmcnt retires in order, so the first counted wait below also covers it
+    for (int64_t it = 0; it < C::RING - 1; ++it)
+        if (it < total) issue(it);
+    for (int i = threadIdx.x; i < MB * 16 * (K / 8); i += 64 * GP_WAVES) {
+        const int m = i / (K / 8), c8 = i % (K / 8);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (m < M) v = *(const u32x4*)(W + (int64_t)m * a.ldw + c8 * 8);
+        *(u32x4*)(wl + m * WSTR + c8 * 16) = v;
+    }
+    f32x4 d[MB];
+    f32x4 dw[NCH][MB];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) dw[ch][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rb = wave & 3, kh = wave >> 2;
+    for (int64_t bi = 0; bi < nmine; ++bi) {
+        const char* ytile = yt + (int)(bi & 1) * YBUF;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int64_t it = bi * NCH + ch;
+#ifndef CAD_EMU
+            if (it + C::RING - 2 < total)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (a Y tile issued behind the chunks only makes this wait stricter)
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            __syncthreads();
+            if (it + C::RING - 1 < total) issue(it + C::RING - 1);
+            if (ch == 0 && bi + 1 < nmine) issue_y(bi + 1);  // a whole block ahead of its use
+            if (ch == 0) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const char* xt = smem + (int)(it % C::RING) * C::XBUF;
+            // (1) out += W . X: transposing reads, as proj_wx_thin_kernel
+#pragma unroll
+            for (int ks = 0; ks < C::KC / 32; ++ks) {
+                const int r0 = ks * 32 + g * 8 + (jl >> 2);
+                const char* p0 = xt + r0 * C::XROW + ((wave ^ gx_swz(r0)) * 32) + (jl & 3) * 8;
+                const char* p1 = xt + (r0 + 4) * C::XROW + ((wave ^ gx_swz(r0 + 4)) * 32) + (jl & 3) * 8;
+                const u32x2 lo = cad_lds_read_tr16(p0), hi = cad_lds_read_tr16(p1);
+                const u32x4 xf = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const u32x4 wf = *(const u32x4*)(wl + (mb * 16 + jl) * WSTR + (ch * C::KC + ks * 32 + g * 8) * 2);
+                    d[mb] = cad_mfma_16x16x32_bf16(xf, wf, d[mb]);
+                }
+            }
+            // (2) dW[chunk rows, :] += X_tile . Y_tile^T over this wave's 64 tokens: A = channel rows rb * 16 .. + 15 (token-
+            // contiguous: eight tokens of a row are one 16-byte piece), B = rows of Y
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int lp = kh * 8 + ks * 4 + g;  // logical 16-byte piece = tokens 8 lp .. 8 lp + 7 of the block
+                const int r = rb * 16 + jl;
+                const int pp = (((lp >> 1) ^ gx_swz(r)) << 1) | (lp & 1);
+                const u32x4 af = *(const u32x4*)(xt + r * C::XROW + pp * 16);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int yr = mb * 16 + jl;
+                    const u32x4 bf = *(const u32x4*)(ytile + yr * C::XROW + ((lp ^ (yr & 15)) * 16));
+                    dw[ch][mb] = cad_mfma_16x16x32_bf16(af, bf, dw[ch][mb]);
+                }
+            }
+            if (ch == NCH - 1) {
+                const int64_t blk = b0 + bi * bstep;
+                const int64_t t = blk * C::NT + wave * 16 + g * 4;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int m = mb * 16 + jl;
+                    u32x2 pk;
+                    pk[0] = cad_pack_bf16x2_safe(d[mb][0], d[mb][1]);
+                    pk[1] = cad_pack_bf16x2_safe(d[mb][2], d[mb][3]);
+                    if (m < M) *(u32x2*)(out + (int64_t)m * a.ldo + t) = pk;
+                }
+            }
+        }
+    }
+    // the two token halves of every accumulator tile meet in LDS (the ring is free now), then the (K, M) partial slot is written
+    __syncthreads();
+    float* ex = (float*)smem;  // [4 channel blocks][NCH][MB][64 lanes][4]
+    if (kh == 1) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) *(f32x4*)(ex + (((rb * NCH + ch) * MB + mb) * 64 + lane) * 4) = dw[ch][mb];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        float* slot = a.wg_partials + (int64_t)blockIdx.x * K * M;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const f32x4 o = *(const f32x4*)(ex + (((rb * NCH + ch) * MB + mb) * 64 + lane) * 4);
+                const int m = mb * 16 + jl;
+                if (m < M) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slot[(int64_t)(ch * C::KC + rb * 16 + g * 4 + r) * M + m] = dw[ch][mb][r] + o[r];
+                }
+            }
+    }
+}
+
 }  // namespace
 
 // more than 64 KB of dynamic LDS has to be requested per kernel: the largest size asked for so far is remembered per
@@ -571,4 +725,33 @@ extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
     CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X | (uintptr_t)a->out | (uintptr_t)a->acc) % 16) == 0);
     CadProfScope prof(8, stream);
     return a->K <= 32 ? launch_wx<1>(a, stream) : launch_wx<2>(a, stream);
+}
+
+extern "C" int cad_proj_wx_wgrad_supported(int M, int K, int64_t T) {
+    return (M == 16 || M == 32) && (K == 256 || K == 512) && T >= GtCfg::NT && (T % GtCfg::NT) == 0;
+}
+extern "C" int cad_proj_wx_wgrad_partials(int64_t T) {
+    const int64_t nblk = T / GtCfg::NT;
+    return (int)(nblk < 256 ? (nblk < 1 ? 1 : nblk) : 256);
+}
+
+template <int MB, int NCH>
+static int launch_wx_wgrad(const cad_proj_args* a, void* stream) {
+    const int gx = cad_proj_wx_wgrad_partials(a->T);
+    const size_t lds = GtCfg::lds(MB * 16, NCH * GtCfg::KC) + 2 * (size_t)MB * 16 * GtCfg::XROW;
+    dim3 grid((unsigned)gx), block(64 * GP_WAVES);
+    GP_BIG_LDS((proj_wx_thin_wgrad_kernel<MB, NCH>), lds);
+    CAD_LAUNCH((proj_wx_thin_wgrad_kernel<MB, NCH>), grid, block, lds, stream, *a);
+    return cad_after_launch();
+}
+
+extern "C" int cad_proj_wx_wgrad(const cad_proj_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->W && a->X && a->out && a->wg_y && a->wg_partials && a->acc == nullptr && a->act == 0);
+    if (!cad_proj_wx_wgrad_supported(a->M, a->K, a->T)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T && a->ld_wg_y >= a->T);
+    CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 4) == 0 && (a->ld_wg_y % 8) == 0);
+    CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X | (uintptr_t)a->wg_y) % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
+    CadProfScope prof(8, stream);
+    if (a->M == 16) return a->K == 256 ? launch_wx_wgrad<1, 4>(a, stream) : launch_wx_wgrad<1, 8>(a, stream);
+    return a->K == 256 ? launch_wx_wgrad<2, 4>(a, stream) : launch_wx_wgrad<2, 8>(a, stream);
 }

@@ -323,11 +323,16 @@ class BiMambaMixerFn(torch.autograd.Function):
                     "cad_reduce_partials")
             L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
                     "cad_reduce_partials")
-            if ops.proj_wx_supported(ddelta, E, T, M=R):
-                ops.proj_wx(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+            if ops.proj_wx_wgrad_supported(ddelta, R, E, T):
+                # d(dt_lr) = W_dt^T d(delta) and dW_dt = d(delta) dt_lr^T from ONE pass over d(delta) (cad_proj_wx_wgrad)
+                _, dW_dt = ops.proj_wx_wgrad(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T),
+                                             dbc[:R].view(R, T), out=ddbc[:R].view(R, T))
             else:
-                torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
-            dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
+                if ops.proj_wx_supported(ddelta, E, T, M=R):
+                    ops.proj_wx(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+                else:
+                    torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+                dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
             # d(xc) = du + W_x^T . d(dbc), in place (no copy of the 268 MB addend)
             if ops.proj_wx_supported(du, R + 2 * N, T):

@@ -609,3 +609,25 @@ def proj_wxT_fp8(Wq: torch.Tensor, sw: torch.Tensor, Xq: torch.Tensor, sx: torch
                       out.stride(0))
     L.check(L.get_lib().cad_proj_wxT_fp8(C.byref(a), stream), "cad_proj_wxT_fp8")
     return out
+
+
+def proj_wx_wgrad_supported(X: torch.Tensor, M: int, K: int, T: int) -> bool:
+    return X.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_wx_wgrad_supported(int(M), int(K), int(T)))
+
+
+def proj_wx_wgrad(W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """(out (M, T) = W (M, K) @ X (K, T),  dW (K, M) fp32 = X (K, T) @ Y (M, T)^T) from ONE pass over X (cad_proj_wx_wgrad):
+    d(dt_lr) = W_dt^T d(delta) together with dW_dt = d(delta) dt_lr^T.  All operands channel-major bf16."""
+    M, K = W.shape
+    T = X.shape[1]
+    if X.shape[0] != K or Y.shape != (M, T) or W.stride(1) != 1 or X.stride(1) != 1 or Y.stride(1) != 1:
+        raise ValueError("proj_wx_wgrad: W (M, K), X (K, T), Y (M, T) with unit inner stride")
+    lib = L.get_lib()
+    if out is None:
+        out = torch.empty((M, T), dtype=torch.bfloat16, device=X.device)
+    part = torch.empty((lib.cad_proj_wx_wgrad_partials(T), K, M), dtype=torch.float32, device=X.device)
+    stream = L.stream_and_check(W, X, Y, out, part, contiguous=False)
+    a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0), None, 0, None, 0,
+                   L.ptr(Y), Y.stride(0), L.ptr(part))
+    L.check(lib.cad_proj_wx_wgrad(C.byref(a), stream), "cad_proj_wx_wgrad")
+    return out, part.sum(dim=0)

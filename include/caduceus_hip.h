@@ -293,6 +293,10 @@ typedef struct {
     int act;           /* 0 = none; CAD_ACT_SOFTPLUS_BIAS: out = softplus(W . X + bias) evaluated in fp32 -- dt_proj + delta_bias +
                         * softplus of mamba_inner_fn / selective_scan_fn(delta_softplus=True) in one pass (the scans then take
                         * delta_is_dt = 1) */
+    /* cad_proj_wx_wgrad only: the second operand Y (M, T) of the weight gradient and the partial-sum buffer (see below) */
+    const void* wg_y;
+    int64_t ld_wg_y;
+    float* wg_partials;
 } cad_proj_args;
 #define CAD_ACT_SOFTPLUS_BIAS 1
 int cad_proj_wxT(const cad_proj_args* a, void* stream);
@@ -306,6 +310,14 @@ int cad_proj_wx_supported(int K, int64_t T);
 /* cad_proj_wx also takes thin M / deep K products without addend (M <= 64, K a multiple of 64 up to 1024, T % 8 == 0; ldo % 4):
  * x_proj (M = dt_rank + 2 d_state, K = d_inner; `x_proj` inside mamba_inner_fn) and d(dt_lr) = W_dt^T . d(delta). */
 int cad_proj_wx_thin_supported(int M, int K, int64_t T);
+/* cad_proj_wx_wgrad: the thin-M / deep-K product  out (M, T) = W (M, K) . X (K, T)  AND, from the same single pass over X, the weight
+ * gradient  dW (K, M) = X (K, T) . Y (M, T)^T  -- d(dt_lr) = W_dt^T . d(delta) together with dW_dt = d(delta) . dt_lr^T of the dt_proj
+ * backward (both stream the (d_inner, T) tensor d(delta); mamba_inner_fn's backward reached from modeling_caduceus.py:128,130).
+ * M in {16, 32}, K in {256, 512} (cad_proj_wx_wgrad_supported), T % 8 == 0, bf16.  wg_partials: cad_proj_wx_wgrad_partials(T) slots of
+ * (K, M) fp32, one per workgroup, WRITTEN (no zeroing needed); dW = the sum over the slots (fixed order: deterministic). */
+int cad_proj_wx_wgrad(const cad_proj_args* a, void* stream);
+int cad_proj_wx_wgrad_supported(int M, int K, int64_t T);
+int cad_proj_wx_wgrad_partials(int64_t T);
 
 /* ---------------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) projections -- BASELINE configs[4] "fp8 MFMA projections": the same `in_proj` nn.Linear call of

@@ -23,7 +23,7 @@ def test_fp8_in_proj_in_the_model(backend):
     name, dev = backend
     model = _model(dev)
     g = torch.Generator().manual_seed(1)
-    ids = torch.randint(7, 11, (1, 40), generator=g).to(dev)
+    ids = torch.randint(7, 11, (1, 64), generator=g).to(dev)  # T = 2 x 64 = 128 tokens: the fused d(dt_lr) + dW_dt kernel is on the path
     labels = ids.clone()
     comp = model.lm_head.complement_map  # (vocabulary padded to a multiple of 8)
 

@@ -130,3 +130,19 @@ def test_fp8_in_proj_quantisation_and_product(backend, case, dtype):
     full = W.double() @ xf.double().t()
     rel = float((out.float().cpu().double() - full).norm() / full.norm())
     assert rel < 6e-2, rel
+
+
+@pytest.mark.parametrize("M,K,T", [(16, 512, 128 * 5), (16, 256, 128 * 3), (32, 512, 128 * 2), (16, 512, 128 * 300)])
+def test_proj_wx_wgrad_fused(backend, M, K, T):
+    """cad_proj_wx_wgrad: d(dt_lr) = W . X and dW = X . Y^T from one pass over X -- the product is bit-identical to the plain thin
+    kernel, the weight gradient equals the fp32 product of the bf16 operands (fp32 accumulation over T in a fixed order)."""
+    name, dev = backend
+    if name == "emu" and T > 128 * 8:
+        pytest.skip("long stream: device only")
+    W, X, Y = _bf(M, K, seed=5) * 0.2, _bf(K, T, seed=6), _bf(M, T, seed=7)
+    out, dW = ops.proj_wx_wgrad(W.to(dev), X.to(dev), Y.to(dev))
+    plain = ops.proj_wx(W.to(dev), X.to(dev))
+    assert torch.equal(out, plain)
+    ref = X.float().double() @ Y.float().double().t()
+    assert dW.shape == (K, M) and dW.dtype == torch.float32
+    torch.testing.assert_close(dW.cpu().double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
