@@ -112,6 +112,8 @@ _SHARED_GATE = os.environ.get("CADUCEUS_AMD_SHARED_GATE", "1") != "0"
 _FUSED_SOFTPLUS = os.environ.get("CADUCEUS_AMD_FUSED_SOFTPLUS", "1") != "0"
 
 
+# d(dt_lr) and dW_dt from one pass over d(delta) (cad_proj_wx_wgrad); CADUCEUS_AMD_FUSED_WGRAD=0 keeps the two-kernel path (A/B switch)
+_FUSED_WGRAD = os.environ.get("CADUCEUS_AMD_FUSED_WGRAD", "1") != "0"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
@@ -323,7 +325,7 @@ class BiMambaMixerFn(torch.autograd.Function):
                     "cad_reduce_partials")
             L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
                     "cad_reduce_partials")
-            if ops.proj_wx_wgrad_supported(ddelta, R, E, T):
+            if _FUSED_WGRAD and ops.proj_wx_wgrad_supported(ddelta, R, E, T):
                 # d(dt_lr) = W_dt^T d(delta) and dW_dt = d(delta) dt_lr^T from ONE pass over d(delta) (cad_proj_wx_wgrad)
                 _, dW_dt = ops.proj_wx_wgrad(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T),
                                              dbc[:R].view(R, T), out=ddbc[:R].view(R, T))
