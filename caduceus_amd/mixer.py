@@ -10,7 +10,10 @@ readable specification).  Scheduling the backward by hand removes what generic a
     fp32 sum, 3-5x faster than the un-split library GEMM;
   * the conv forward / backward of both parameter sets run as one launch each (x read once, dx = dx_f + dx_r written once); dB/dC partial sums are reduced straight into the rows of
     the x_proj gradient operand; du is folded into the x_proj backward GEMM (addmm).
-All kernels are the C-ABI entry points of include/caduceus_hip.h; GEMMs are hipBLASLt through torch.
+All kernels are the C-ABI entry points of include/caduceus_hip.h.  Projections: in_proj, x_proj, dt_proj (+ bias + softplus), d(y),
+d(dt_lr) + dW_dt (one pass, cad_proj_wx_wgrad) and the x_proj input gradient run on the library's own MFMA kernels (csrc/gemm.hip,
+gemm_fp8.hip); out_proj forward, d(x2d) and the three remaining weight gradients are hipBLASLt through torch.
+Scan launches with fewer workgroups than the GPU has CUs are L-split (ops.lsplit_factor).
 """
 from __future__ import annotations
 
