@@ -132,6 +132,7 @@ SYMBOLS = {
     "cad_proj_wx_wgrad": (_i, [C.POINTER(ProjArgs), _p]),
     "cad_proj_wx_wgrad_supported": (_i, [_i, _i, _i64]),
     "cad_proj_wx_wgrad_partials": (_i, [_i64]),
+    "cad_proj_wgrad_only_supported": (_i, [_i, _i, _i64]),
     "cad_quant_rows_fp8": (_i, [C.POINTER(QuantFp8Args), _p]),
     "cad_proj_wxT_fp8": (_i, [C.POINTER(ProjFp8Args), _p]),
     "cad_proj_fp8_supported": (_i, [_i]),

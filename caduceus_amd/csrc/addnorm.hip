@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_kernel(cad_add_nor
     TY* y = (TY*)a.y;
     const float invD = 1.0f / (float)D;
     for (int64_t row = (int64_t)blockIdx.x * AN_WAVES + wave; row < nrows; row += (int64_t)gridDim.x * AN_WAVES) {
-        const int s = (int)(row / R);
+        const int s = row >= R ? 1 : 0;  // n_strands <= 2 (a 64-bit division per row costs more than the row's arithmetic)
         const int64_t r = row - (int64_t)s * R;
         const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
         float v[AN_KMAX];
@@ -83,9 +83,14 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_kernel(cad_add_nor
 }
 
 // Backward: rows are indexed in the INPUT index space; dy / dres_out / sum_saved are read through the map.
-#define ANB_ROWS_PER_WAVE 8
+// Rows one backward wave walks before the workgroup folds its dweight / dbias sums into the result (LDS + one atomic per
+// channel): chosen per launch.  The fold is what a short walk pays for -- 0.262 ms at 8 rows, 0.249 at 32, 0.222 at 64 for the
+// configs[2] layer (262144 rows of 256 channels; 128 rows leave too few workgroups: 0.327 ms) -- profiles/r03_ab_conv_addnorm.txt
+#define ANB_ROWS_MIN 8
+#define ANB_ROWS_MAX 64
+#define ANB_TARGET_BLOCKS 1024
 template <typename TX, typename TY>
-__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_kernel(cad_add_norm_bwd_args a) {
+__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_kernel(cad_add_norm_bwd_args a, int rows_per_wave) {
     __shared__ float red[AN_WAVES][64 * AN_KMAX];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -99,11 +104,11 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_kernel(cad_add_nor
     float dw[AN_KMAX], db[AN_KMAX];
 #pragma unroll
     for (int k = 0; k < AN_KMAX; ++k) dw[k] = db[k] = 0.f;
-    const int64_t row0 = ((int64_t)blockIdx.x * AN_WAVES + wave) * ANB_ROWS_PER_WAVE;
-    for (int i = 0; i < ANB_ROWS_PER_WAVE; ++i) {
+    const int64_t row0 = ((int64_t)blockIdx.x * AN_WAVES + wave) * rows_per_wave;
+    for (int i = 0; i < rows_per_wave; ++i) {
         const int64_t row = row0 + i;
         if (row >= nrows) break;
-        const int s = (int)(row / R);
+        const int s = row >= R ? 1 : 0;  // n_strands <= 2 (a 64-bit division per row costs more than the row's arithmetic)
         const int64_t r = row - (int64_t)s * R;
         const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
         const float rstd = a.rstd[row];
@@ -177,7 +182,8 @@ __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float* o) {
     o[2] = cad_bits2f(t.w[1] << 16), o[3] = cad_bits2f(t.w[1] & 0xffff0000u);
 }
 
-template <typename TX, typename TY>
+// KMAX = 256-channel steps per lane: 1 for D <= 256 (a third of the registers of the general instantiation, twice the waves per SIMD)
+template <typename TX, typename TY, int KMAX>
 __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add_norm_args a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -188,13 +194,13 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add
     TY* y = (TY*)a.y;
     const float invD = 1.0f / (float)D;
     for (int64_t row = (int64_t)blockIdx.x * AN_WAVES + wave; row < nrows; row += (int64_t)gridDim.x * AN_WAVES) {
-        const int s = (int)(row / R);
+        const int s = row >= R ? 1 : 0;  // n_strands <= 2 (a 64-bit division per row costs more than the row's arithmetic)
         const int64_t r = row - (int64_t)s * R;
         const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
-        float v[ANV_KMAX][4];
+        float v[KMAX][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < ANV_KMAX; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             const int c = (lane + 64 * k) * 4;
             if (c < D) {
                 ld4<TX>(x + row * D + c, v[k]);
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add
             mean = s1 * invD;
             float qq = 0.f;
 #pragma unroll
-            for (int k = 0; k < ANV_KMAX; ++k) {
+            for (int k = 0; k < KMAX; ++k) {
                 const int c = (lane + 64 * k) * 4;
                 if (c < D) {
 #pragma unroll
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add
             if (a.mean) a.mean[row] = mean;
         }
 #pragma unroll
-        for (int k = 0; k < ANV_KMAX; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             const int c = (lane + 64 * k) * 4;
             if (c < D) {
                 const int oc = a.swap_flip ? (D - 4 - c) : c;  // first of the 4 output channels
@@ -262,9 +268,9 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add
     }
 }
 
-template <typename TX, typename TY>
-__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_vec_kernel(cad_add_norm_bwd_args a) {
-    __shared__ float red[AN_WAVES][64 * ANV_KMAX * 4];
+template <typename TX, typename TY, int KMAX>
+__global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_vec_kernel(cad_add_norm_bwd_args a, int rows_per_wave) {
+    __shared__ float red[AN_WAVES][64 * KMAX * 4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t R = a.rows_per_strand;
@@ -273,35 +279,45 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_vec_kernel(cad_add
     const TY* dy = (const TY*)a.dy;
     TX* dx = (TX*)a.dx;
     const float invD = 1.0f / (float)D;
-    float dw[ANV_KMAX][4], db[ANV_KMAX][4];  // indexed by OUTPUT channel oc + q
+    float dw[KMAX][4], db[KMAX][4];  // indexed by OUTPUT channel oc + q
 #pragma unroll
-    for (int k = 0; k < ANV_KMAX; ++k)
+    for (int k = 0; k < KMAX; ++k)
 #pragma unroll
         for (int q = 0; q < 4; ++q) dw[k][q] = db[k][q] = 0.f;
-    const int64_t row0 = ((int64_t)blockIdx.x * AN_WAVES + wave) * ANB_ROWS_PER_WAVE;
-    for (int i = 0; i < ANB_ROWS_PER_WAVE; ++i) {
+    float wreg[KMAX][4];  // the norm weight of this lane's OUTPUT channels, loaded once
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = (lane + 64 * k) * 4;
+        if (c < D) {
+            ld4<float>(a.weight + (a.swap_flip ? (D - 4 - c) : c), wreg[k]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wreg[k][q] = 0.f;
+        }
+    }
+    const int64_t row0 = ((int64_t)blockIdx.x * AN_WAVES + wave) * rows_per_wave;
+    for (int i = 0; i < rows_per_wave; ++i) {
         const int64_t row = row0 + i;
         if (row >= nrows) break;
-        const int s = (int)(row / R);
+        const int s = row >= R ? 1 : 0;  // n_strands <= 2 (a 64-bit division per row costs more than the row's arithmetic)
         const int64_t r = row - (int64_t)s * R;
         const int64_t orow = a.swap_flip ? ((int64_t)(a.n_strands - 1 - s) * R + r) : row;
         const float rstd = a.rstd[row];
         const float mean = (a.is_rms || !a.mean) ? 0.f : a.mean[row];
-        float g[ANV_KMAX][4], xh[ANV_KMAX][4];  // output-channel order
+        float g[KMAX][4], xh[KMAX][4];  // output-channel order
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int k = 0; k < ANV_KMAX; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             const int c = (lane + 64 * k) * 4;
             if (c < D) {
                 const int oc = a.swap_flip ? (D - 4 - c) : c;
-                float dyv[4], sm[4], w[4];
+                float dyv[4], sm[4];
                 ld4<TY>(dy + orow * D + oc, dyv);
                 ld4<float>(a.sum_saved + orow * D + oc, sm);
-                ld4<float>(a.weight + oc, w);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     xh[k][q] = (sm[q] - mean) * rstd;
-                    g[k][q] = dyv[q] * w[q];
+                    g[k][q] = dyv[q] * wreg[k][q];
                     sg += g[k][q];
                     sgx += g[k][q] * xh[k][q];
                     dw[k][q] += dyv[q] * xh[k][q];
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_vec_kernel(cad_add
         sgx = wave_sum(sgx) * invD;
         sg = a.is_rms ? 0.f : wave_sum(sg) * invD;
 #pragma unroll
-        for (int k = 0; k < ANV_KMAX; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             const int c = (lane + 64 * k) * 4;
             if (c < D) {
                 const int oc = a.swap_flip ? (D - 4 - c) : c;
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_vec_kernel(cad_add
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1 && !a.dbias) break;
 #pragma unroll
-        for (int k = 0; k < ANV_KMAX; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             const int c = (lane + 64 * k) * 4;
             const int oc = a.swap_flip ? (D - 4 - c) : c;
 #pragma unroll
@@ -367,8 +383,10 @@ extern "C" int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream) {
                                           (uintptr_t)a->bias | (uintptr_t)a->y | (uintptr_t)a->residual_out) % 16) == 0;
 #define AN_FWD(TX, TY)                                                                  \
     do {                                                                                \
-        if (vec)                                                                        \
-            CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY>), grid, block, 0, stream, *a);  \
+        if (vec && a->D <= 256)                                                         \
+            CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, 1>), grid, block, 0, stream, *a);  \
+        else if (vec)                                                                   \
+            CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, ANV_KMAX>), grid, block, 0, stream, *a);  \
         else                                                                            \
             CAD_LAUNCH((add_norm_fwd_kernel<TX, TY>), grid, block, 0, stream, *a);      \
     } while (0)
@@ -389,16 +407,21 @@ extern "C" int cad_add_norm_bwd(const cad_add_norm_bwd_args* a, void* stream) {
     if (a->D > 64 * AN_KMAX) return CAD_ERR_UNSUPPORTED;
     CadProfScope prof(5, stream);
     const int64_t nrows = a->rows_per_strand * a->n_strands;
-    const int64_t per_block = (int64_t)AN_WAVES * ANB_ROWS_PER_WAVE;
+    int64_t rpw = nrows / ((int64_t)AN_WAVES * ANB_TARGET_BLOCKS);
+    rpw = rpw < ANB_ROWS_MIN ? ANB_ROWS_MIN : (rpw > ANB_ROWS_MAX ? ANB_ROWS_MAX : rpw);
+    const int rows_per_wave = (int)rpw;
+    const int64_t per_block = (int64_t)AN_WAVES * rows_per_wave;
     dim3 grid((unsigned)((nrows + per_block - 1) / per_block)), block(64 * AN_WAVES);
     const bool vec = (a->D % 4) == 0 && (((uintptr_t)a->dy | (uintptr_t)a->dres_out | (uintptr_t)a->sum_saved |
                                           (uintptr_t)a->weight | (uintptr_t)a->dx | (uintptr_t)a->dres_in) % 16) == 0;
 #define AN_BWD(TX, TY)                                                                  \
     do {                                                                                \
-        if (vec)                                                                        \
-            CAD_LAUNCH((add_norm_bwd_vec_kernel<TX, TY>), grid, block, 0, stream, *a);  \
+        if (vec && a->D <= 256)                                                         \
+            CAD_LAUNCH((add_norm_bwd_vec_kernel<TX, TY, 1>), grid, block, 0, stream, *a, rows_per_wave);  \
+        else if (vec)                                                                   \
+            CAD_LAUNCH((add_norm_bwd_vec_kernel<TX, TY, ANV_KMAX>), grid, block, 0, stream, *a, rows_per_wave);  \
         else                                                                            \
-            CAD_LAUNCH((add_norm_bwd_kernel<TX, TY>), grid, block, 0, stream, *a);      \
+            CAD_LAUNCH((add_norm_bwd_kernel<TX, TY>), grid, block, 0, stream, *a, rows_per_wave);      \
     } while (0)
     if (a->x_dtype == CAD_F32 && a->y_dtype == CAD_F32)
         AN_BWD(float, float);

@@ -21,7 +21,11 @@ namespace {
 #define CV_HALO (CV_KMAX - 1)
 #define CV_WAVE_POS (62 * CV_VEC)                 // useful positions per wave tile
 #define CV_TILES_BWD 8                            // wave tiles a backward workgroup walks before reducing dw / dbias
+#define CV_TILES_FWD 4                            // wave tiles a forward wave walks (the next tile's load in flight under the arithmetic)
 #define CV_MAXSETS 2
+#ifndef CV_BWD_WAVES
+#define CV_BWD_WAVES 4                            // waves per SIMD the backward is compiled for (<= 128 VGPRs)
+#endif
 
 struct ConvFwdSets {
     cad_conv1d_args s[CV_MAXSETS];
@@ -47,6 +51,66 @@ __device__ __forceinline__ void load8(const T* row, int64_t l0, int64_t L, bool 
         for (int j = 0; j < CV_VEC; ++j) {
             const int64_t l = l0 + j;
             out[j] = (l >= 0 && l < L) ? to_f32(row[l]) : 0.f;
+        }
+    }
+}
+// the same 8 positions as they lie in memory (zeros outside [0, L)), converted later: the load of the NEXT tile is issued before
+// the arithmetic of the current one, so a wave keeps two tiles in flight
+// Raw tiles are kept as opaque 32-bit words: a vector of 16-bit elements is taken apart by the compiler right behind its load (and
+// the load is then waited for at once), words are only touched where cvt8 unpacks them.
+template <typename T>
+struct __attribute__((aligned(sizeof(T) * CV_VEC))) CvRaw {
+    uint32_t w[sizeof(T) * CV_VEC / 4];
+};
+template <typename T, bool VEC>
+__device__ __forceinline__ CvRaw<T> load8_raw(const T* row, int64_t l0, int64_t L) {
+    CvRaw<T> r;
+    if constexpr (VEC) {
+        // L % 8 == 0 and l0 % 8 == 0: a vector lies either inside [0, L) or outside.  The load is UNCONDITIONAL (from a clamped
+        // address; cvt8 zeroes a vector that lay outside): a load under a divergent branch is waited for at the end of the branch
+        int64_t lc = l0 < 0 ? 0 : l0;
+        lc = lc < L ? lc : L - CV_VEC;
+        r = *(const CvRaw<T>*)(row + lc);
+    } else {
+        T e[CV_VEC];
+#pragma unroll
+        for (int j = 0; j < CV_VEC; ++j) {
+            const int64_t l = l0 + j;
+            e[j] = (l >= 0 && l < L) ? row[l] : from_f32<T>(0.f);
+        }
+        __builtin_memcpy(&r, e, sizeof(r));
+    }
+    return r;
+}
+template <typename T, bool VEC>
+__device__ __forceinline__ void cvt8(const CvRaw<T>& r, int64_t l0, int64_t L, float* out) {
+    const bool inside = !VEC || (l0 >= 0 && l0 < L);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < CV_VEC / 2; ++j) {
+            out[2 * j] = inside ? cad_bits2f(r.w[j] << 16) : 0.f;
+            out[2 * j + 1] = inside ? cad_bits2f(r.w[j] & 0xffff0000u) : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CV_VEC; ++j) out[j] = inside ? cad_bits2f(r.w[j]) : 0.f;
+    }
+}
+// VEC: one vector store or nothing
+template <typename T, bool VEC>
+__device__ __forceinline__ void store8v(T* row, int64_t l0, int64_t L, const float* v) {
+    if constexpr (VEC) {
+        if (l0 >= 0 && l0 < L) {
+            CvVec<T> tmp;
+#pragma unroll
+            for (int j = 0; j < CV_VEC; ++j) tmp.v[j] = from_f32<T>(v[j]);
+            *(CvVec<T>*)(row + l0) = tmp;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CV_VEC; ++j) {
+            const int64_t l = l0 + j;
+            if (l >= 0 && l < L) row[l] = from_f32<T>(v[j]);
         }
     }
 }
@@ -98,7 +162,7 @@ struct DirTag {
     static constexpr int value = REV;
 };
 
-template <typename T, int NSETS>
+template <typename T, int NSETS, bool VEC>
 __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets) {
     const cad_conv1d_args& a0 = sets.s[0];
     const int64_t rowid = blockIdx.x;  // e * SB + sb
@@ -108,44 +172,48 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
     const T* x = (const T*)a0.x + rowid * L;
-    bool vec_ok = (L % CV_VEC) == 0 && ((uintptr_t)a0.x % (sizeof(T) * CV_VEC)) == 0;
     float W4[NSETS][CV_KMAX], bias[NSETS];
     int revs[NSETS];
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const cad_conv1d_args& a = sets.s[s];
-        vec_ok = vec_ok && ((uintptr_t)a.out % (sizeof(T) * CV_VEC)) == 0;
         revs[s] = sb < a.split ? a.rev_lo : a.rev_hi;
         load_w4(a.w, e, a.K, W4[s]);
         bias[s] = a.bias ? a.bias[e] : 0.f;
     }
-    const int64_t tile = (int64_t)blockIdx.y * CV_WAVES + wave;
-    const int64_t l0 = tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
-    if (tile * CV_WAVE_POS >= L) return;  // wave-uniform
-    float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO];
-    load8(x, l0, L, vec_ok, own);
-    halo_window(own, xe);
+    const int64_t tile0 = (int64_t)blockIdx.y * CV_TILES_FWD * CV_WAVES + wave;
+    if (tile0 * CV_WAVE_POS >= L) return;  // wave-uniform
     const bool useful = lane >= 1 && lane <= 62;
+    CvRaw<T> raw = load8_raw<T, VEC>(x, tile0 * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC, L);
+    for (int it = 0; it < CV_TILES_FWD; ++it) {
+        const int64_t tile = tile0 + (int64_t)it * CV_WAVES;  // the workgroup's waves cover 4 neighbouring tiles at a time
+        if (tile * CV_WAVE_POS >= L) break;                   // wave-uniform
+        const int64_t l0 = tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
+        float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO];
+        cvt8<T, VEC>(raw, l0, L, own);
+        if (it + 1 < CV_TILES_FWD && (tile + CV_WAVES) * CV_WAVE_POS < L) raw = load8_raw<T, VEC>(x, l0 + (int64_t)CV_WAVES * CV_WAVE_POS, L);
+        halo_window(own, xe);
 #pragma unroll
-    for (int s = 0; s < NSETS; ++s) {
-        float o[CV_VEC];
-        auto body = [&](auto dir) {
-            constexpr int REV = decltype(dir)::value;
+        for (int s = 0; s < NSETS; ++s) {
+            float o[CV_VEC];
+            auto body = [&](auto dir) {
+                constexpr int REV = decltype(dir)::value;
 #pragma unroll
-            for (int j = 0; j < CV_VEC; ++j) {
-                const float acc = conv4<REV>(W4[s], xe + j, bias[s]);
-                o[j] = acc * cad_sigmoid(acc);
-            }
-        };
-        if (revs[s]) body(DirTag<1>{}); else body(DirTag<0>{});
-        if (useful) store8((T*)sets.s[s].out + rowid * L, l0, L, vec_ok, o);
+                for (int j = 0; j < CV_VEC; ++j) {
+                    const float acc = conv4<REV>(W4[s], xe + j, bias[s]);
+                    o[j] = acc * cad_sigmoid(acc);
+                }
+            };
+            if (revs[s]) body(DirTag<1>{}); else body(DirTag<0>{});
+            if (useful) store8v<T, VEC>((T*)sets.s[s].out + rowid * L, l0, L, o);
+        }
     }
 }
 
 // Backward.  dpre[l] = dout[l] * silu'(pre[l]);  dx = sum over the sets of the transposed conv of dpre (the taps of
 // the opposite direction);  dw[k] = sum_l dpre[l] * x[l + offset_k];  dbias = sum_l dpre[l].
-template <typename T, int NSETS>
-__global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets) {
+template <typename T, int NSETS, bool VEC, bool ACC>
+__global__ __launch_bounds__(CV_THREADS, CV_BWD_WAVES) void conv1d_bwd_kernel(ConvBwdSets sets) {
     __shared__ float red[CV_WAVES][NSETS][CV_KMAX + 1];
     const cad_conv1d_bwd_args& a0 = sets.s[0];
     const int64_t rowid = blockIdx.x;
@@ -156,13 +224,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets
     const int wave = cad_uniform(threadIdx.x >> 6);
     const T* x = (const T*)a0.x + rowid * L;
     T* dx = (T*)a0.dx + rowid * L;
-    bool vec_ok = (L % CV_VEC) == 0 && (((uintptr_t)a0.x | (uintptr_t)a0.dx) % (sizeof(T) * CV_VEC)) == 0;
     float W4[NSETS][CV_KMAX], bias[NSETS], part[NSETS][CV_KMAX + 1];  // part: dw4[0..3], dbias
     int revs[NSETS];
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const cad_conv1d_bwd_args& a = sets.s[s];
-        vec_ok = vec_ok && ((uintptr_t)a.dout % (sizeof(T) * CV_VEC)) == 0;
         revs[s] = sb < a.split ? a.rev_lo : a.rev_hi;
         load_w4(a.w, e, a.K, W4[s]);
 #pragma unroll
@@ -170,23 +236,37 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets
         bias[s] = a.bias ? a.bias[e] : 0.f;
     }
     const float useful = (lane >= 1 && lane <= 62) ? 1.f : 0.f;
+    // all loads of a tile (x, the dx addend, dout of every set) are issued one tile ahead, raw, and converted when the tile is computed
+    // (the dx addend is loaded at the start of its own tile and added last: the arithmetic of the tile covers most of its latency)
+    CvRaw<T> rx, rg[NSETS];
+    auto fetch = [&](int64_t l0) {
+        rx = load8_raw<T, VEC>(x, l0, L);
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) rg[s] = load8_raw<T, VEC>((const T*)sets.s[s].dout + rowid * L, l0, L);
+    };
+    {
+        const int64_t tile = (int64_t)blockIdx.y * CV_TILES_BWD * CV_WAVES + wave;
+        if (tile * CV_WAVE_POS < L) fetch(tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC);
+    }
     for (int it = 0; it < CV_TILES_BWD; ++it) {
         const int64_t tile = ((int64_t)blockIdx.y * CV_TILES_BWD + it) * CV_WAVES + wave;
         if (tile * CV_WAVE_POS >= L) break;  // wave-uniform
         const int64_t l0 = tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
         float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO], o[CV_VEC];
-        load8(x, l0, L, vec_ok, own);
-        halo_window(own, xe);
-        if (a0.accumulate) {
-            load8(dx, l0, L, vec_ok, o);
-        } else {
+        cvt8<T, VEC>(rx, l0, L, own);
+        CvRaw<T> rdx;  // (ACC is a template parameter: a run-time branch would merge the register behind it and wait for the load there)
+        if constexpr (ACC) rdx = load8_raw<T, VEC>((const T*)dx, l0, L);
 #pragma unroll
-            for (int j = 0; j < CV_VEC; ++j) o[j] = 0.f;
-        }
+        for (int j = 0; j < CV_VEC; ++j) o[j] = 0.f;
+        CvRaw<T> cg[NSETS];  // this tile's dout, still raw: converted set by set
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) cg[s] = rg[s];
+        if (it + 1 < CV_TILES_BWD && (tile + CV_WAVES) * CV_WAVE_POS < L) fetch(l0 + (int64_t)CV_WAVES * CV_WAVE_POS);
+        halo_window(own, xe);
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
             float g[CV_VEC], dpre[CV_VEC], dpe[CV_VEC + 2 * CV_HALO];
-            load8((const T*)sets.s[s].dout + rowid * L, l0, L, vec_ok, g);
+            cvt8<T, VEC>(cg[s], l0, L, g);
             auto body = [&](auto dir) {
                 constexpr int REV = decltype(dir)::value;
 #pragma unroll
@@ -207,7 +287,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_bwd_kernel(ConvBwdSets sets
             };
             if (revs[s]) body(DirTag<1>{}); else body(DirTag<0>{});
         }
-        if (useful != 0.f) store8(dx, l0, L, vec_ok, o);
+        if constexpr (ACC) {
+            float add[CV_VEC];
+            cvt8<T, VEC>(rdx, l0, L, add);
+#pragma unroll
+            for (int j = 0; j < CV_VEC; ++j) o[j] += add[j];
+        }
+        if (useful != 0.f) store8v<T, VEC>(dx, l0, L, o);
     }
     // workgroup reduction of the dw / dbias partials, then a handful of atomics per workgroup
 #pragma unroll
@@ -256,22 +342,28 @@ extern "C" int cad_conv1d_fwd_multi(const cad_conv1d_args* sets, int nsets, void
     for (int i = nsets; i < CV_MAXSETS; ++i) ks.s[i] = sets[0];
     const cad_conv1d_args* a = &sets[0];
     CadProfScope prof(2, stream);
-    const int64_t per_block = (int64_t)CV_WAVES * CV_WAVE_POS;
+    const int64_t per_block = (int64_t)CV_WAVES * CV_WAVE_POS * CV_TILES_FWD;
     dim3 grid((unsigned)((int64_t)a->E * a->SB), (unsigned)((a->L + per_block - 1) / per_block)), block(CV_THREADS);
     if (grid.y > 65535u) return CAD_ERR_UNSUPPORTED;
+    const size_t vb = (a->dtype == CAD_F32 ? 4 : 2) * CV_VEC;
+    uintptr_t ptrs = (uintptr_t)a->x;
+    for (int i = 0; i < nsets; ++i) ptrs |= (uintptr_t)sets[i].out;
+    const bool vec = (a->L % CV_VEC) == 0 && (ptrs % vb) == 0;
+#define CV_FWD(T, NS)                                                                   \
+    do {                                                                                \
+        if (vec)                                                                        \
+            CAD_LAUNCH((conv1d_fwd_kernel<T, NS, true>), grid, block, 0, stream, ks);   \
+        else                                                                            \
+            CAD_LAUNCH((conv1d_fwd_kernel<T, NS, false>), grid, block, 0, stream, ks);  \
+    } while (0)
     if (a->dtype == CAD_F32) {
-        if (nsets == 1)
-            CAD_LAUNCH((conv1d_fwd_kernel<float, 1>), grid, block, 0, stream, ks);
-        else
-            CAD_LAUNCH((conv1d_fwd_kernel<float, 2>), grid, block, 0, stream, ks);
+        if (nsets == 1) CV_FWD(float, 1); else CV_FWD(float, 2);
     } else if (a->dtype == CAD_BF16) {
-        if (nsets == 1)
-            CAD_LAUNCH((conv1d_fwd_kernel<bf16_t, 1>), grid, block, 0, stream, ks);
-        else
-            CAD_LAUNCH((conv1d_fwd_kernel<bf16_t, 2>), grid, block, 0, stream, ks);
+        if (nsets == 1) CV_FWD(bf16_t, 1); else CV_FWD(bf16_t, 2);
     } else {
         return CAD_ERR_UNSUPPORTED;
     }
+#undef CV_FWD
     return cad_after_launch();
 }
 
@@ -295,19 +387,29 @@ extern "C" int cad_conv1d_bwd_multi(const cad_conv1d_bwd_args* sets, int nsets, 
     const int64_t per_block = (int64_t)CV_WAVES * CV_WAVE_POS * CV_TILES_BWD;
     dim3 grid((unsigned)((int64_t)a->E * a->SB), (unsigned)((a->L + per_block - 1) / per_block)), block(CV_THREADS);
     if (grid.y > 65535u) return CAD_ERR_UNSUPPORTED;
+    const size_t vb = (a->dtype == CAD_F32 ? 4 : 2) * CV_VEC;
+    uintptr_t ptrs = (uintptr_t)a->x | (uintptr_t)a->dx;
+    for (int i = 0; i < nsets; ++i) ptrs |= (uintptr_t)sets[i].dout;
+    const bool vec = (a->L % CV_VEC) == 0 && (ptrs % vb) == 0;
+#define CV_BWD(T, NS)                                                                   \
+    do {                                                                                \
+        if (vec && a->accumulate)                                                              \
+            CAD_LAUNCH((conv1d_bwd_kernel<T, NS, true, true>), grid, block, 0, stream, ks);    \
+        else if (vec)                                                                          \
+            CAD_LAUNCH((conv1d_bwd_kernel<T, NS, true, false>), grid, block, 0, stream, ks);   \
+        else if (a->accumulate)                                                                \
+            CAD_LAUNCH((conv1d_bwd_kernel<T, NS, false, true>), grid, block, 0, stream, ks);   \
+        else                                                                                   \
+            CAD_LAUNCH((conv1d_bwd_kernel<T, NS, false, false>), grid, block, 0, stream, ks);  \
+    } while (0)
     if (a->dtype == CAD_F32) {
-        if (nsets == 1)
-            CAD_LAUNCH((conv1d_bwd_kernel<float, 1>), grid, block, 0, stream, ks);
-        else
-            CAD_LAUNCH((conv1d_bwd_kernel<float, 2>), grid, block, 0, stream, ks);
+        if (nsets == 1) CV_BWD(float, 1); else CV_BWD(float, 2);
     } else if (a->dtype == CAD_BF16) {
-        if (nsets == 1)
-            CAD_LAUNCH((conv1d_bwd_kernel<bf16_t, 1>), grid, block, 0, stream, ks);
-        else
-            CAD_LAUNCH((conv1d_bwd_kernel<bf16_t, 2>), grid, block, 0, stream, ks);
+        if (nsets == 1) CV_BWD(bf16_t, 1); else CV_BWD(bf16_t, 2);
     } else {
         return CAD_ERR_UNSUPPORTED;
     }
+#undef CV_BWD
     return cad_after_launch();
 }
 

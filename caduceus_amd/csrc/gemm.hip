@@ -364,6 +364,7 @@ struct GtCfg {
     static constexpr size_t lds(int M, int K) { return (size_t)RING * XBUF + (size_t)((M + 15) / 16 * 16) * (K * 2 + 16); }
 };
 static_assert(GtCfg::DPW == 2, "the counted waits below assume two DMA instructions per wave and chunk");
+static_assert((GtCfg::RING & (GtCfg::RING - 1)) == 0, "ring slots are advanced with a mask");
 
 __device__ __forceinline__ void gt_issue_chunk(const bf16_t* X, int64_t ldx, int k0, int64_t t0, int64_t T, char* xbuf, int wave,
                                                int lane) {
@@ -399,12 +400,21 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
     const int64_t total = nmine * NCH;               // (block, chunk) iterations of this workgroup
     char* wl = smem + C::RING * C::XBUF;             // W copy: row stride WSTR (padded: the 16 rows of a B fragment read spread over the banks)
     const int WSTR = K * 2 + 16;
-    auto issue = [&](int64_t it) {
-        const int64_t blk = b0 + (it / NCH) * bstep;
-        gt_issue_chunk(X, a.ldx, (int)(it % NCH) * C::KC, blk * C::NT, T, smem + (int)(it % C::RING) * C::XBUF, wave, lane);
+    // the (block, chunk) position of the next chunk to issue and of the chunk being consumed are carried as counters: a 64-bit
+    // division by the run-time NCH per chunk (scalar long division, ~150 instructions, twice per iteration between the barrier
+    // and the next DMA issue) made this kernel 1.5x slower than the weight-gradient kernel below on the same operand
+    int ich = 0, islot = 0;
+    int64_t iblk = b0;
+    auto issue_next = [&]() {
+        gt_issue_chunk(X, a.ldx, ich * C::KC, iblk * C::NT, T, smem + islot * C::XBUF, wave, lane);
+        islot = (islot + 1) & (C::RING - 1);
+        if (++ich == NCH) {
+            ich = 0;
+            iblk += bstep;
+        }
     };
     for (int64_t it = 0; it < C::RING - 1; ++it)
-        if (it < total) issue(it);
+        if (it < total) issue_next();
     // W -> LDS (rows >= M zero)
     for (int i = threadIdx.x; i < MB * 16 * (K / 8); i += 64 * GP_WAVES) {
         const int m = i / (K / 8), c8 = i % (K / 8);
@@ -413,8 +423,9 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
         *(u32x4*)(wl + m * WSTR + c8 * 16) = v;
     }
     f32x4 d[MB];
+    int ch = 0, slot = 0;
+    int64_t blk = b0;
     for (int64_t it = 0; it < total; ++it) {
-        const int ch = (int)(it % NCH);
         // chunk `it` has landed: of this wave's DMA, at most the two later chunks (4 instructions) may still be in flight --
         // fewer near the end of the stream, where everything is waited for
 #ifndef CAD_EMU
@@ -424,12 +435,12 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         __syncthreads();  // every wave's share of the chunk is visible; the tile consumed LAST iteration is free again
-        if (it + C::RING - 1 < total) issue(it + C::RING - 1);
+        if (it + C::RING - 1 < total) issue_next();
         if (ch == 0) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const char* xt = smem + (int)(it % C::RING) * C::XBUF;
+        const char* xt = smem + slot * C::XBUF;
 #pragma unroll
         for (int ks = 0; ks < C::KC / 32; ++ks) {
             const int r0 = ks * 32 + g * 8 + (jl >> 2);
@@ -443,8 +454,8 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
                 d[mb] = cad_mfma_16x16x32_bf16(xf, wf, d[mb]);
             }
         }
-        if (ch == NCH - 1) {
-            const int64_t blk = b0 + (it / NCH) * bstep;
+        slot = (slot + 1) & (C::RING - 1);
+        if (++ch == NCH) {
             const int64_t t = blk * C::NT + wave * 16 + g * 4;  // this lane's four consecutive tokens
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -454,6 +465,8 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
                 pk[1] = cad_pack_bf16x2_safe(d[mb][2], d[mb][3]);
                 if (m < M && t + 4 <= T) *(u32x2*)(out + (int64_t)m * a.ldo + t) = pk;
             }
+            ch = 0;
+            blk += bstep;
         }
     }
 }
@@ -469,7 +482,8 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
 // accumulator tiles per wave (the chunk loop is unrolled, so the tiles are addressed statically).  Wave w owns channel block w & 3
 // of every chunk and the token half w >> 2; the halves are summed through LDS at the end and the workgroup writes its (K, M) fp32
 // partial slot; the caller sums the <= 256 slots (fixed order).
-template <int MB, int NCH>
+// PROD = false: the weight gradient alone (a.W / a.out unused) -- dW_x = xc . d(dbc)^T of the x_proj backward (M = dt_rank + 2 d_state).
+template <int MB, int NCH, bool PROD>
 __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(cad_proj_args a) {
     typedef GtCfg C;
     CAD_DYN_SMEM(char, smem);
@@ -495,27 +509,33 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
         const int64_t blk = b0 + (it / NCH) * bstep;
         gt_issue_chunk(X, a.ldx, (int)(it % NCH) * C::KC, blk * C::NT, T, smem + (int)(it % C::RING) * C::XBUF, wave, lane);
     };
-    // Y tile of block number bi (of this workgroup): MB * 4 DMA instructions of four rows each, one per wave 0 .. MB * 4 - 1;
+    // Y tile of block number bi (of this workgroup): MB * 4 DMA instructions of four rows each, dealt over the waves;
     // physical 16-byte piece pp of row r holds logical piece pp ^ (r & 15): the 16 rows a B-fragment read touches hit 16 distinct
     // pieces = all 64 banks
     auto issue_y = [&](int64_t bi) {
-        if (wave < MB * 4) {
-            const int row = wave * 4 + (lane >> 4), pp = lane & 15;
-            const int lp = pp ^ (row & 15);
-            const int64_t blk = b0 + bi * bstep;
-            const int rr = row < M ? row : M - 1;  // rows >= M: valid data, their columns of the result are never stored
-            cad_glds16(Y + (int64_t)rr * a.ld_wg_y + blk * C::NT + lp * 8,
-                       cad_uniform((int)(cad_lds_off(yt) + (int)(bi & 1) * YBUF + wave * 1024)));
+#pragma unroll
+        for (int q0 = 0; q0 < MB * 4; q0 += GP_WAVES) {
+            const int q = q0 + wave;
+            if (q < MB * 4) {
+                const int row = q * 4 + (lane >> 4), pp = lane & 15;
+                const int lp = pp ^ (row & 15);
+                const int64_t blk = b0 + bi * bstep;
+                const int rr = row < M ? row : M - 1;  // rows >= M: valid data, their columns of the result are never stored
+                cad_glds16(Y + (int64_t)rr * a.ld_wg_y + blk * C::NT + lp * 8,
+                           cad_uniform((int)(cad_lds_off(yt) + (int)(bi & 1) * YBUF + q * 1024)));
+            }
         }
     };
     issue_y(0);  // BEFORE the chunks: vmcnt retires in order, so the first counted wait below also covers it
     for (int64_t it = 0; it < C::RING - 1; ++it)
         if (it < total) issue(it);
-    for (int i = threadIdx.x; i < MB * 16 * (K / 8); i += 64 * GP_WAVES) {
-        const int m = i / (K / 8), c8 = i % (K / 8);
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (m < M) v = *(const u32x4*)(W + (int64_t)m * a.ldw + c8 * 8);
-        *(u32x4*)(wl + m * WSTR + c8 * 16) = v;
+    if constexpr (PROD) {
+        for (int i = threadIdx.x; i < MB * 16 * (K / 8); i += 64 * GP_WAVES) {
+            const int m = i / (K / 8), c8 = i % (K / 8);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < M) v = *(const u32x4*)(W + (int64_t)m * a.ldw + c8 * 8);
+            *(u32x4*)(wl + m * WSTR + c8 * 16) = v;
+        }
     }
     f32x4 d[MB];
     f32x4 dw[NCH][MB];
@@ -538,12 +558,13 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
             __syncthreads();
             if (it + C::RING - 1 < total) issue(it + C::RING - 1);
             if (ch == 0 && bi + 1 < nmine) issue_y(bi + 1);  // a whole block ahead of its use
-            if (ch == 0) {
+            if (PROD && ch == 0) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) d[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const char* xt = smem + (int)(it % C::RING) * C::XBUF;
             // (1) out += W . X: transposing reads, as proj_wx_thin_kernel
+            if constexpr (PROD) {
 #pragma unroll
             for (int ks = 0; ks < C::KC / 32; ++ks) {
                 const int r0 = ks * 32 + g * 8 + (jl >> 2);
@@ -556,6 +577,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
                     const u32x4 wf = *(const u32x4*)(wl + (mb * 16 + jl) * WSTR + (ch * C::KC + ks * 32 + g * 8) * 2);
                     d[mb] = cad_mfma_16x16x32_bf16(xf, wf, d[mb]);
                 }
+            }
             }
             // (2) dW[chunk rows, :] += X_tile . Y_tile^T over this wave's 64 tokens: A = channel rows rb * 16 .. + 15 (token-
             // contiguous: eight tokens of a row are one 16-byte piece), B = rows of Y
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
                     dw[ch][mb] = cad_mfma_16x16x32_bf16(af, bf, dw[ch][mb]);
                 }
             }
-            if (ch == NCH - 1) {
+            if (PROD && ch == NCH - 1) {
                 const int64_t blk = b0 + bi * bstep;
                 const int64_t t = blk * C::NT + wave * 16 + g * 4;
 #pragma unroll
@@ -730,28 +752,49 @@ extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
 extern "C" int cad_proj_wx_wgrad_supported(int M, int K, int64_t T) {
     return (M == 16 || M == 32) && (K == 256 || K == 512) && T >= GtCfg::NT && (T % GtCfg::NT) == 0;
 }
+// the weight gradient alone (cad_proj_args.W == NULL, out == NULL): any M <= 64
+extern "C" int cad_proj_wgrad_only_supported(int M, int K, int64_t T) {
+    return M >= 1 && M <= 64 && (K == 256 || K == 512) && T >= GtCfg::NT && (T % GtCfg::NT) == 0;
+}
 extern "C" int cad_proj_wx_wgrad_partials(int64_t T) {
     const int64_t nblk = T / GtCfg::NT;
     return (int)(nblk < 256 ? (nblk < 1 ? 1 : nblk) : 256);
 }
 
-template <int MB, int NCH>
+template <int MB, int NCH, bool PROD>
 static int launch_wx_wgrad(const cad_proj_args* a, void* stream) {
     const int gx = cad_proj_wx_wgrad_partials(a->T);
-    const size_t lds = GtCfg::lds(MB * 16, NCH * GtCfg::KC) + 2 * (size_t)MB * 16 * GtCfg::XROW;
+    size_t lds = GtCfg::lds(MB * 16, NCH * GtCfg::KC) + 2 * (size_t)MB * 16 * GtCfg::XROW;
+    const size_t exch = (size_t)4 * NCH * MB * 1024;  // the final exchange of the accumulator tiles reuses the front of the LDS
+    if (lds < exch) lds = exch;
     dim3 grid((unsigned)gx), block(64 * GP_WAVES);
-    GP_BIG_LDS((proj_wx_thin_wgrad_kernel<MB, NCH>), lds);
-    CAD_LAUNCH((proj_wx_thin_wgrad_kernel<MB, NCH>), grid, block, lds, stream, *a);
+    GP_BIG_LDS((proj_wx_thin_wgrad_kernel<MB, NCH, PROD>), lds);
+    CAD_LAUNCH((proj_wx_thin_wgrad_kernel<MB, NCH, PROD>), grid, block, lds, stream, *a);
     return cad_after_launch();
 }
 
 extern "C" int cad_proj_wx_wgrad(const cad_proj_args* a, void* stream) {
-    CAD_CHECK_ARG(a && a->W && a->X && a->out && a->wg_y && a->wg_partials && a->acc == nullptr && a->act == 0);
-    if (!cad_proj_wx_wgrad_supported(a->M, a->K, a->T)) return CAD_ERR_UNSUPPORTED;
-    CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T && a->ld_wg_y >= a->T);
-    CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 4) == 0 && (a->ld_wg_y % 8) == 0);
-    CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X | (uintptr_t)a->wg_y) % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
+    CAD_CHECK_ARG(a && a->X && a->wg_y && a->wg_partials && a->acc == nullptr && a->act == 0);
+    CAD_CHECK_ARG(a->ldx >= a->T && a->ld_wg_y >= a->T && (a->ldx % 8) == 0 && (a->ld_wg_y % 8) == 0);
+    CAD_CHECK_ARG((((uintptr_t)a->X | (uintptr_t)a->wg_y) % 16) == 0);
     CadProfScope prof(8, stream);
-    if (a->M == 16) return a->K == 256 ? launch_wx_wgrad<1, 4>(a, stream) : launch_wx_wgrad<1, 8>(a, stream);
-    return a->K == 256 ? launch_wx_wgrad<2, 4>(a, stream) : launch_wx_wgrad<2, 8>(a, stream);
+    if (a->W == nullptr && a->out == nullptr) {  // weight gradient alone
+        if (!cad_proj_wgrad_only_supported(a->M, a->K, a->T)) return CAD_ERR_UNSUPPORTED;
+        const int mb = (a->M + 15) / 16;
+#define GW_ONLY(MB_)                                                                                     \
+    return a->K == 256 ? launch_wx_wgrad<MB_, 4, false>(a, stream) : launch_wx_wgrad<MB_, 8, false>(a, stream)
+        switch (mb) {
+            case 1: GW_ONLY(1);
+            case 2: GW_ONLY(2);
+            case 3: GW_ONLY(3);
+            default: GW_ONLY(4);
+        }
+#undef GW_ONLY
+    }
+    CAD_CHECK_ARG(a->W && a->out);
+    if (!cad_proj_wx_wgrad_supported(a->M, a->K, a->T)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG(a->ldw >= a->K && a->ldo >= a->T && (a->ldw % 8) == 0 && (a->ldo % 4) == 0);
+    CAD_CHECK_ARG(((uintptr_t)a->W % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
+    if (a->M == 16) return a->K == 256 ? launch_wx_wgrad<1, 4, true>(a, stream) : launch_wx_wgrad<1, 8, true>(a, stream);
+    return a->K == 256 ? launch_wx_wgrad<2, 4, true>(a, stream) : launch_wx_wgrad<2, 8, true>(a, stream);
 }

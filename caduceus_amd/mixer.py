@@ -117,6 +117,8 @@ _FUSED_SOFTPLUS = os.environ.get("CADUCEUS_AMD_FUSED_SOFTPLUS", "1") != "0"
 
 # d(dt_lr) and dW_dt from one pass over d(delta) (cad_proj_wx_wgrad); CADUCEUS_AMD_FUSED_WGRAD=0 keeps the two-kernel path (A/B switch)
 _FUSED_WGRAD = os.environ.get("CADUCEUS_AMD_FUSED_WGRAD", "1") != "0"
+# dW_x = d(dbc) . xc^T on the weight-gradient stage of the same kernel (W == NULL) instead of the GEMM library + a partial sum
+_OWN_DWX = os.environ.get("CADUCEUS_AMD_OWN_DWX", "1") != "0"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
@@ -338,7 +340,10 @@ class BiMambaMixerFn(torch.autograd.Function):
                 else:
                     torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
                 dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
-            dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
+            if _OWN_DWX and ops.proj_wgrad_only_supported(xc, R + 2 * N, E, T):
+                dW_x = ops.proj_wgrad_only(xc.view(E, T), ddbc.view(R + 2 * N, T))
+            else:
+                dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
             # d(xc) = du + W_x^T . d(dbc), in place (no copy of the 268 MB addend)
             if ops.proj_wx_supported(du, R + 2 * N, T):
                 ops.proj_wx(wT["x"][i] if wT else w_x.t().contiguous(), ddbc.view(R + 2 * N, T), out=du.view(E, T),

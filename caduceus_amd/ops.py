@@ -631,3 +631,22 @@ def proj_wx_wgrad(W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, out: Option
                    L.ptr(Y), Y.stride(0), L.ptr(part))
     L.check(lib.cad_proj_wx_wgrad(C.byref(a), stream), "cad_proj_wx_wgrad")
     return out, part.sum(dim=0)
+
+
+def proj_wgrad_only_supported(X: torch.Tensor, M: int, K: int, T: int) -> bool:
+    return X.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_wgrad_only_supported(int(M), int(K), int(T)))
+
+
+def proj_wgrad_only(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """dW (M, K) fp32 = Y (M, T) @ X (K, T)^T, both channel-major bf16, M <= 64: the weight-gradient stage of cad_proj_wx_wgrad
+    alone (W == NULL) -- dW_x = d(dbc) . xc^T of the x_proj backward."""
+    K, T = X.shape
+    M = Y.shape[0]
+    if Y.shape[1] != T or X.stride(1) != 1 or Y.stride(1) != 1:
+        raise ValueError("proj_wgrad_only: X (K, T), Y (M, T) with unit inner stride")
+    lib = L.get_lib()
+    part = torch.empty((lib.cad_proj_wx_wgrad_partials(T), K, M), dtype=torch.float32, device=X.device)
+    stream = L.stream_and_check(X, Y, part, contiguous=False)
+    a = L.ProjArgs(None, L.ptr(X), None, T, M, K, 0, X.stride(0), 0, None, 0, None, 0, L.ptr(Y), Y.stride(0), L.ptr(part))
+    L.check(lib.cad_proj_wx_wgrad(C.byref(a), stream), "cad_proj_wx_wgrad")
+    return part.permute(0, 2, 1).sum(dim=0)

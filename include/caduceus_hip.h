@@ -317,6 +317,9 @@ int cad_proj_wx_thin_supported(int M, int K, int64_t T);
  * (K, M) fp32, one per workgroup, WRITTEN (no zeroing needed); dW = the sum over the slots (fixed order: deterministic). */
 int cad_proj_wx_wgrad(const cad_proj_args* a, void* stream);
 int cad_proj_wx_wgrad_supported(int M, int K, int64_t T);
+/* With W == NULL and out == NULL the same entry point computes the weight gradient alone, for any M <= 64
+ * (cad_proj_wgrad_only_supported): dW_x = xc . d(dbc)^T of the x_proj backward (M = dt_rank + 2 d_state). */
+int cad_proj_wgrad_only_supported(int M, int K, int64_t T);
 int cad_proj_wx_wgrad_partials(int64_t T);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -1,5 +1,7 @@
 """Per-kernel parity of the C-ABI ops against the CPU oracle, on the host emulator (CPU) and on the GPU (-m gpu).
 Edge cases follow the reference tests' spirit: ragged / tiny / multi-chunk lengths, both directions, odd d_state."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -92,7 +94,7 @@ def test_selective_scan_golden(backend, shape, golden_dir):
 
 
 @pytest.mark.parametrize("case", [(5, 2, 75, 4, 1, 0, 1), (3, 1, 8, 4, 1, 1, 1), (4, 3, 2100, 3, 1, 0, 1),
-                                  (2, 1, 1, 4, 0, 0, 0), (6, 2, 4096, 2, 2, 1, 0)])
+                                  (2, 1, 1, 4, 0, 0, 0), (6, 2, 4096, 2, 2, 1, 0), (2, 2, 17000, 4, 1, 0, 1)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_causal_conv1d(backend, case, dtype):
     name, dev = backend
@@ -174,6 +176,33 @@ def test_add_norm(backend, S, R, D, is_rms, swap_flip, xdt, ydt):
                 torch.testing.assert_close(a.grad.float().cpu(), r.grad, rtol=tol["rtol"], atol=tol["atol"] * sc)
 
 
+@pytest.mark.parametrize("S,R,D,xdt", [(2, 40001, 64, torch.bfloat16), (1, 300007, 30, torch.float32)])
+def test_add_norm_many_rows(backend, S, R, D, xdt):
+    """Row counts at which the backward walks more than its minimum of 8 rows per wave (the launcher aims at ~1024 workgroups: 19 rows
+    per wave for 80002 rows, the maximum of 64 for 300007) with a ragged last workgroup; vector and scalar kernels."""
+    name, dev = backend
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(S, 1, R, D, generator=g).to(xdt).float()
+    res = torch.randn(S, 1, R, D, generator=g)
+    w = 1 + 0.2 * torch.randn(D, generator=g)
+    gy, gr = torch.randn(S, 1, R, D, generator=g), torch.randn(S, 1, R, D, generator=g)
+    swap = S == 2
+    ins = [leaf(x, dev, xdt), leaf(res, dev), leaf(w, dev)]
+    y, s = ops.add_norm(ins[0], ins[1], ins[2], None, 1e-5, True, swap, xdt)
+    ((y.float() * gy.to(dev)).sum() + (s * gr.to(dev)).sum()).backward()
+    rins = [leaf(x, 'cpu'), leaf(res, 'cpu'), leaf(w, 'cpu')]
+    ry, rs = _ref_add_norm(rins[0], rins[1], rins[2], None, 1e-5, True, swap)
+    ((ry * gy).sum() + (rs * gr).sum()).backward()
+    tol = FP32 if xdt == torch.float32 else BF16
+    torch.testing.assert_close(y.float().cpu(), ry.detach(), **tol)
+    for a, r in zip(ins[:2], rins[:2]):
+        sc = max(1.0, float(r.grad.abs().max()))
+        torch.testing.assert_close(a.grad.float().cpu(), r.grad, rtol=tol["rtol"], atol=tol["atol"] * sc)
+    # the weight gradient sums R * S rows: tolerance relative to its size
+    sc = float(rins[2].grad.abs().max())
+    torch.testing.assert_close(ins[2].grad.cpu(), rins[2].grad, rtol=2e-3 if xdt == torch.float32 else 2e-2, atol=2e-3 * sc)
+
+
 @pytest.mark.parametrize("n_strands", [1, 2])
 def test_embed(backend, n_strands):
     name, dev = backend
@@ -220,7 +249,7 @@ def test_lm_head_and_loss(backend, n_strands, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(5, 2, 75, 4), (3, 3, 2100, 3), (6, 2, 4096, 4)])
+@pytest.mark.parametrize("case", [(5, 2, 75, 4), (3, 3, 2100, 3), (6, 2, 4096, 4), (2, 2, 34000, 4)])
 def test_causal_conv1d_two_sets(backend, case, dtype):
     """cad_conv1d_fwd_multi / cad_conv1d_bwd_multi (two parameter sets on one x, opposite directions, dx summed) are
     identical to two single-set launches."""
@@ -247,6 +276,18 @@ def test_causal_conv1d_two_sets(backend, case, dtype):
         torch.testing.assert_close(grads[i][0], wi.grad.view(E, K), rtol=1e-4, atol=1e-4 * max(1.0, float(wi.grad.abs().max())))
         torch.testing.assert_close(grads[i][1], bi.grad, rtol=1e-4, atol=1e-4 * max(1.0, float(bi.grad.abs().max())))
     torch.testing.assert_close(dx.float(), dx_ref, **(FP32 if dtype == torch.float32 else BF16))
+    # the C-ABI's accumulate flag: set 0 written, set 1 added to it (one launch each)
+    from caduceus_amd import _lib as CL
+    dx2 = torch.empty_like(x)
+    for i in range(2):
+        wf, bf = params[i]
+        dw, db = torch.zeros_like(wf), torch.zeros_like(bf)
+        stream = CL.stream_and_check(x, wf, bf, douts[i], dx2, dw, db)
+        a = CL.Conv1dBwdArgs(CL.ptr(x), CL.ptr(wf), CL.ptr(bf), CL.ptr(douts[i]), CL.ptr(dx2), CL.ptr(dw), CL.ptr(db), SB, L, split,
+                             E, K, dirs[i][0], dirs[i][1], CL.dtype_code(x.dtype), i)
+        CL.check(CL.get_lib().cad_conv1d_bwd(ctypes.byref(a), stream), "cad_conv1d_bwd")
+        torch.testing.assert_close(dw, grads[i][0], rtol=1e-5, atol=1e-5 * max(1.0, float(dw.abs().max())))
+    torch.testing.assert_close(dx2.float(), dx_ref, **(FP32 if dtype == torch.float32 else BF16))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -146,3 +146,19 @@ def test_proj_wx_wgrad_fused(backend, M, K, T):
     ref = X.float().double() @ Y.float().double().t()
     assert dW.shape == (K, M) and dW.dtype == torch.float32
     torch.testing.assert_close(dW.cpu().double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,T", [(48, 512, 128 * 70), (40, 256, 128 * 5), (24, 512, 128 * 300), (64, 256, 128 * 9), (7, 512, 128)])
+def test_proj_wgrad_only(backend, M, K, T):
+    """cad_proj_wx_wgrad with W == NULL: dW = Y . X^T alone (dW_x = d(dbc) . xc^T of the x_proj backward), any M <= 64, against the
+    fp64 product of the same bf16 operands."""
+    dev = backend[1]
+    g = torch.Generator().manual_seed(M * 7 + K)
+    X = torch.randn(K, T, generator=g).to(torch.bfloat16)
+    Y = torch.randn(M, T, generator=g).to(torch.bfloat16)
+    assert ops.proj_wgrad_only_supported(X.to(dev), M, K, T)
+    assert not ops.proj_wgrad_only_supported(X.to(dev), 65, K, T)
+    dW = ops.proj_wgrad_only(X.to(dev), Y.to(dev))
+    ref = Y.double() @ X.double().t()
+    assert dW.shape == (M, K) and dW.dtype == torch.float32
+    torch.testing.assert_close(dW.cpu().double(), ref, rtol=1e-4, atol=1e-3 * (T / 128) ** 0.5)

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--strands", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--ab", default=None, help="mixer module switch (e.g. _OWN_DWX) to toggle IN THIS PROCESS: blocks of --reps "
+                    "layers alternate on / off for --rounds rounds, so both arms see the same clocks and power state")
+    ap.add_argument("--rounds", type=int, default=4)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -46,6 +49,22 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    if a.ab:
+        ms = {True: [], False: []}
+        for _ in range(a.rounds):
+            for on in (True, False):
+                setattr(mixer, a.ab, on)
+                step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    step()
+                e1.record()
+                torch.cuda.synchronize()
+                ms[on].append(round(e0.elapsed_time(e1) / a.reps, 3))
+        print(json.dumps({"ab": a.ab, "on_ms": ms[True], "off_ms": ms[False],
+                          "on_mean": round(sum(ms[True]) / a.rounds, 3), "off_mean": round(sum(ms[False]) / a.rounds, 3)}))
+        return
     _lib.prof_reset()
     _lib.prof_enable(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
