@@ -279,6 +279,26 @@ __device__ __forceinline__ f32x4 cad_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 
     return __builtin_bit_cast(f32x4, r);
 }
 #endif
+// v_mfma_f32_16x16x4_f32:  D (16 x 16 fp32) = A (16 x 4 fp32) * B (4 x 16 fp32) + C.  Lane l, g = l >> 4:  A: row l & 15, k = g;
+// B: k = g, column l & 15;  C / D as above (column l & 15, rows 4g + r).  Full fp32 operands: the LM head keeps its fp32 weight.
+#ifdef CAD_EMU
+__device__ __forceinline__ f32x4 cad_mfma_16x16x4_f32(float a, float b, f32x4 c) {
+    const int lane = emu::lane_id();
+    const int col = lane & 15, rg = lane >> 4;
+    f32x4 d = c;
+    for (int k = 0; k < 4; ++k) {
+        const float bk = emu_exchange(b, k * 16 + col);
+        for (int r = 0; r < 4; ++r) d[r] += emu_exchange(a, k * 16 + 4 * rg + r) * bk;
+    }
+    return d;
+}
+#else
+__device__ __forceinline__ f32x4 cad_mfma_16x16x4_f32(float a, float b, f32x4 c) {
+    typedef float f32x4_hw __attribute__((ext_vector_type(4)));
+    const f32x4_hw r = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, __builtin_bit_cast(f32x4_hw, c), 0, 0, 0);
+    return __builtin_bit_cast(f32x4, r);
+}
+#endif
 // ds_read_b64_tr_b16: transposing LDS read for 16-bit elements.  Within every 16-lane group, lane 4 r + c (r, c in 0..3)
 // supplies the address of 4 contiguous elements S[r][4c .. 4c+3] of a 4 x 16 block S; lane l of the group receives the
 // COLUMN  (S[0][l], S[1][l], S[2][l], S[3][l]).  This is how a [k][token] tile (token-contiguous, as the channel-major

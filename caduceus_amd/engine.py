@@ -63,6 +63,15 @@ def bimamba_tframe(hn: torch.Tensor, mamba_fwd, mamba_rev, strategy: Optional[st
     """BiMambaWrapper (+ RCPSWrapper when hn has two strands) on normed t-frame input hn (S, B, L, D).
 
     strand_swap=True is the RCPS case: rows of strand 1 run every parameter set in the opposite direction."""
+    dev = hn.device.type
+    if torch.is_autocast_enabled(dev) and torch.get_autocast_dtype(dev) != hn.dtype:
+        # a float16 request is computed in fp32 (mamba.act_dtype_of): keep autocast from re-casting the GEMMs in here
+        with torch.autocast(dev, enabled=False):
+            return _bimamba_tframe(hn, mamba_fwd, mamba_rev, strategy, strand_swap)
+    return _bimamba_tframe(hn, mamba_fwd, mamba_rev, strategy, strand_swap)
+
+
+def _bimamba_tframe(hn: torch.Tensor, mamba_fwd, mamba_rev, strategy: Optional[str], strand_swap: bool) -> torch.Tensor:
     S, B, L, D = hn.shape
     SB, T = S * B, S * B * L
     act = hn.dtype

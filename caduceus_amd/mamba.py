@@ -15,9 +15,9 @@ from torch import nn
 from . import engine, ops
 
 
-def act_dtype_of(x: torch.Tensor) -> torch.dtype:
-    """Compute dtype of the kernels for input x: the autocast dtype when autocast is on (the reference trains under
-    AMP, configs/experiment/hg38/hg38.yaml:20), else the dtype of x.  fp32 and bf16 are implemented."""
+def requested_dtype(x: torch.Tensor) -> torch.dtype:
+    """The dtype the caller asked for: the autocast dtype when autocast is on (the reference trains under AMP,
+    configs/experiment/hg38/hg38.yaml:20), else the dtype of x."""
     dt = x.dtype
     dev = x.device.type
     try:
@@ -25,9 +25,24 @@ def act_dtype_of(x: torch.Tensor) -> torch.dtype:
             dt = torch.get_autocast_dtype(dev)
     except (TypeError, RuntimeError):
         pass
+    return dt
+
+
+def act_dtype_of(x: torch.Tensor) -> torch.dtype:
+    """Compute dtype of the kernels for input x.  fp32 and bf16 are implemented; a float16 request (the reference's own AMP
+    precision, and vep_embeddings.py:352) is COMPUTED BY THE FP32 KERNELS -- at least as accurate as fp16 arithmetic, no fp16
+    instantiations of the kernels -- and the module outputs are rounded to float16 (as_requested)."""
+    dt = requested_dtype(x)
+    if dt == torch.float16:
+        return torch.float32
     if dt not in (torch.float32, torch.bfloat16):
         raise NotImplementedError(f"caduceus_amd computes in float32 or bfloat16 (requested {dt}); on MI355X use bf16")
     return dt
+
+
+def as_requested(t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Output t of a module called with input x: float16 when float16 was requested (see act_dtype_of), else unchanged."""
+    return t.to(torch.float16) if requested_dtype(x) == torch.float16 else t
 
 
 class Mamba(nn.Module):
@@ -77,7 +92,7 @@ class Mamba(nn.Module):
             raise NotImplementedError("step-wise inference cache is outside the pre-training hot path")
         act = act_dtype_of(hidden_states)
         out = engine.bimamba_tframe(hidden_states.to(act).unsqueeze(0), self, None, None, strand_swap=False)
-        return out[0]
+        return as_requested(out[0], hidden_states)
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         raise NotImplementedError("step-wise inference cache is outside the pre-training hot path")
@@ -105,7 +120,7 @@ def _norm_fn(x, weight, bias, residual, prenorm, eps, is_rms):
     if xs.dtype not in (torch.float32, act):
         xs = xs.to(act)
     y, res = ops.add_norm(xs, rs, weight, bias, eps, is_rms, False, act)
-    y = y.reshape(shape)
+    y = as_requested(y.reshape(shape), x)
     return y if not prenorm else (y, res.reshape(shape))
 
 
@@ -149,7 +164,7 @@ class Block(nn.Module):
             h = h.to(act)
         r = None if residual is None else residual.unsqueeze(0).float()
         out, res = self.forward_tframe(h, r, act)
-        return out[0], res[0]
+        return as_requested(out[0], hidden_states), res[0]
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)

@@ -294,6 +294,7 @@ class BiMambaMixerFn(torch.autograd.Function):
         fix_cnt = [zbuf[10].view(torch.int32), zbuf[11].view(torch.int32)]
         n_fix = lib.cad_scan_gate_fix_entries(E, SB, Lq)
         fix_list = [torch.empty((n_fix,), dtype=torch.int64, device=x2d.device) for _ in range(2)]
+        wg_dt = wg_x = None  # fp32 partial slots of the own weight-gradient kernels, both sets
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
             N = A.shape[1]
@@ -331,9 +332,13 @@ class BiMambaMixerFn(torch.autograd.Function):
             L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
                     "cad_reduce_partials")
             if _FUSED_WGRAD and ops.proj_wx_wgrad_supported(ddelta, R, E, T):
-                # d(dt_lr) = W_dt^T d(delta) and dW_dt = d(delta) dt_lr^T from ONE pass over d(delta) (cad_proj_wx_wgrad)
-                _, dW_dt = ops.proj_wx_wgrad(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T),
-                                             dbc[:R].view(R, T), out=ddbc[:R].view(R, T))
+                # d(dt_lr) = W_dt^T d(delta) and dW_dt = d(delta) dt_lr^T from ONE pass over d(delta) (cad_proj_wx_wgrad); the
+                # partial slots of both parameter sets are folded by one sum after the loop
+                if wg_dt is None:
+                    wg_dt = ops.wgrad_partials(T, E, R, xc.device, nsets=2)
+                ops.proj_wx_wgrad(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T),
+                                  dbc[:R].view(R, T), out=ddbc[:R].view(R, T), part=wg_dt[i])
+                dW_dt = None
             else:
                 if ops.proj_wx_supported(ddelta, E, T, M=R):
                     ops.proj_wx(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
@@ -341,7 +346,10 @@ class BiMambaMixerFn(torch.autograd.Function):
                     torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
                 dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             if _OWN_DWX and ops.proj_wgrad_only_supported(xc, R + 2 * N, E, T):
-                dW_x = ops.proj_wgrad_only(xc.view(E, T), ddbc.view(R + 2 * N, T))
+                if wg_x is None:
+                    wg_x = ops.wgrad_partials(T, E, R + 2 * N, xc.device, nsets=2)
+                ops.proj_wgrad_only(xc.view(E, T), ddbc.view(R + 2 * N, T), part=wg_x[i])
+                dW_x = None
             else:
                 dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
             # d(xc) = du + W_x^T . d(dbc), in place (no copy of the 268 MB addend)
@@ -354,9 +362,14 @@ class BiMambaMixerFn(torch.autograd.Function):
             part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
         conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs,
                             bufs=[(zbuf[5 * i + 3], zbuf[5 * i + 4] if sets[i][7] is not None else None) for i in range(2)])
+        # one fold per weight for BOTH sets' partial slots (fixed order): (2, P, K, M) -> (2, K, M) / (2, M, K)
+        sum_dt = None if wg_dt is None else wg_dt.sum(dim=1)
+        sum_x = None if wg_x is None else wg_x.permute(0, 1, 3, 2).sum(dim=1)
         for i in range(2):
             meta = pmeta[i]
             (dwc, dbc_conv), (dW_x, dW_dt, dbias, dA_log, dD) = conv_g[i], part[i]
+            dW_x = sum_x[i] if dW_x is None else dW_x
+            dW_dt = sum_dt[i] if dW_dt is None else dW_dt
             grads += [dwc.reshape(meta[0][1]).to(meta[0][0]), None if dbc_conv is None else dbc_conv.to(meta[1][0]),
                       dW_x.to(meta[2][0]), dW_dt.to(meta[3][0]), dbias.to(meta[4][0]), dA_log.to(meta[5][0]),
                       dD.to(meta[6][0])]

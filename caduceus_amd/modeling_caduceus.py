@@ -18,7 +18,7 @@ from transformers.modeling_outputs import BaseModelOutputWithNoAttention, Masked
 from . import engine, ops
 from . import mixer as mixer_sched
 from .configuration_caduceus import CaduceusConfig
-from .mamba import Block, Mamba, RMSNorm, act_dtype_of, norm_params
+from .mamba import Block, Mamba, RMSNorm, act_dtype_of, as_requested, norm_params
 from .modeling_rcps import RCPSAddNormWrapper, RCPSEmbedding, RCPSLMHead, RCPSMambaBlock, RCPSWrapper
 
 
@@ -81,7 +81,7 @@ class BiMambaWrapper(nn.Module):
         if inference_params is not None:
             raise NotImplementedError("step-wise inference cache is outside the pre-training hot path")
         act = act_dtype_of(hidden_states)
-        return self.forward_tframe(hidden_states.to(act).unsqueeze(0), strand_swap=False)[0]
+        return as_requested(self.forward_tframe(hidden_states.to(act).unsqueeze(0), strand_swap=False)[0], hidden_states)
 
     def allocate_inference_cache(self, *args, **kwargs):
         raise NotImplementedError("step-wise inference cache is outside the pre-training hot path")
@@ -167,8 +167,9 @@ class CaduceusMixerModel(nn.Module):
         """Mixer forward: returns (hidden_states (B, L, 2D | D), all_hidden_states)."""
         collect = [] if output_hidden_states else None
         hidden = self.forward_tframe(input_ids, inputs_embeds, collect)
-        all_hidden_states = [engine.from_tframe(h) for h in collect] if collect is not None else []
-        return engine.from_tframe(hidden), all_hidden_states
+        like = inputs_embeds if inputs_embeds is not None else self.embeddings.word_embeddings.weight
+        all_hidden_states = [as_requested(engine.from_tframe(h), like) for h in collect] if collect is not None else []
+        return as_requested(engine.from_tframe(hidden), like), all_hidden_states
 
 
 def _first(outputs):
@@ -349,7 +350,7 @@ class CaduceusForMaskedLM(CaduceusPreTrainedModel):
                 loss = cross_entropy(logits, labels, ignore_index=ignore_index) if fused_loss else None
         if labels is not None and loss_weights is not None:
             loss = weighted_cross_entropy(logits, labels, loss_weights, ignore_index=ignore_index)
-        all_hidden = tuple(engine.from_tframe(h) for h in collect) if collect is not None else None
+        all_hidden = tuple(as_requested(engine.from_tframe(h), logits) for h in collect) if collect is not None else None
         if not return_dict:
             output = (logits,) + ((all_hidden,) if output_hidden_states else ())
             return (loss,) + output if loss is not None else output
@@ -453,7 +454,7 @@ class CaduceusForSequenceClassification(CaduceusPreTrainedModel):
         if len(pooled) == 2:
             logits = (logits + self.score(pooled[1].to(wdt))) / 2
         loss = self._sequence_loss(logits, labels) if labels is not None else None
-        hidden = tuple(engine.from_tframe(h) for h in collect) if collect is not None else None
+        hidden = tuple(as_requested(engine.from_tframe(h), logits) for h in collect) if collect is not None else None
         if not return_dict:
             out = (logits,) + ((hidden,) if hidden is not None else ())
             return ((loss,) + out) if loss is not None else out

@@ -11,7 +11,7 @@ import torch
 from torch import Tensor, nn
 
 from . import engine, ops
-from .mamba import RMSNorm, act_dtype_of, norm_params
+from .mamba import RMSNorm, act_dtype_of, as_requested, norm_params
 
 
 def _comp_tensor(complement_map: dict) -> Tensor:
@@ -71,7 +71,7 @@ class RCPSWrapper(nn.Module):
         if hasattr(self.submodule, "forward_tframe"):
             kwargs.pop("inference_params", None)
             act = act_dtype_of(x)
-            return engine.from_tframe(self.forward_tframe(engine.to_tframe(x.to(act), True)))
+            return as_requested(engine.from_tframe(self.forward_tframe(engine.to_tframe(x.to(act), True))), x)
         n_channels = x.shape[-1]
         fwd_out = self.submodule(x[..., :n_channels // 2], **kwargs)
         rc_out = self.submodule(self.rc(x[..., n_channels // 2:]), **kwargs)
@@ -98,7 +98,7 @@ class RCPSAddNormWrapper(RCPSWrapper):
             t = t.to(act)
         r = None if residual is None else engine.to_tframe(residual.float(), True)
         y, res = self.forward_tframe(t, r, act)
-        y = engine.from_tframe(y)
+        y = as_requested(engine.from_tframe(y), x)
         return y if not prenorm else (y, engine.from_tframe(res))
 
 
@@ -134,7 +134,7 @@ class RCPSMambaBlock(nn.Module):
             h = h.to(act)
         r = None if residual is None else engine.to_tframe(residual.float(), True)
         out, res = self.forward_tframe(h, r, act)
-        return engine.from_tframe(out), engine.from_tframe(res)
+        return as_requested(engine.from_tframe(out), hidden_states), engine.from_tframe(res)
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)

@@ -615,9 +615,17 @@ def proj_wx_wgrad_supported(X: torch.Tensor, M: int, K: int, T: int) -> bool:
     return X.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_wx_wgrad_supported(int(M), int(K), int(T)))
 
 
-def proj_wx_wgrad(W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, out: Optional[torch.Tensor] = None):
+def wgrad_partials(T: int, K: int, M: int, device, nsets: int = 1) -> torch.Tensor:
+    """(nsets, P, K, M) fp32 partial slots of cad_proj_wx_wgrad, one (K, M) slot per workgroup: a caller with several parameter sets
+    hands each launch its own [i] and folds all of them with ONE sum over dim 1 afterwards."""
+    return torch.empty((nsets, L.get_lib().cad_proj_wx_wgrad_partials(T), K, M), dtype=torch.float32, device=device)
+
+
+def proj_wx_wgrad(W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, out: Optional[torch.Tensor] = None,
+                  part: Optional[torch.Tensor] = None):
     """(out (M, T) = W (M, K) @ X (K, T),  dW (K, M) fp32 = X (K, T) @ Y (M, T)^T) from ONE pass over X (cad_proj_wx_wgrad):
-    d(dt_lr) = W_dt^T d(delta) together with dW_dt = d(delta) dt_lr^T.  All operands channel-major bf16."""
+    d(dt_lr) = W_dt^T d(delta) together with dW_dt = d(delta) dt_lr^T.  All operands channel-major bf16.
+    part: a (P, K, M) slice of wgrad_partials() -- then the partial slots are left un-summed (returns (out, None))."""
     M, K = W.shape
     T = X.shape[1]
     if X.shape[0] != K or Y.shape != (M, T) or W.stride(1) != 1 or X.stride(1) != 1 or Y.stride(1) != 1:
@@ -625,28 +633,32 @@ def proj_wx_wgrad(W: torch.Tensor, X: torch.Tensor, Y: torch.Tensor, out: Option
     lib = L.get_lib()
     if out is None:
         out = torch.empty((M, T), dtype=torch.bfloat16, device=X.device)
-    part = torch.empty((lib.cad_proj_wx_wgrad_partials(T), K, M), dtype=torch.float32, device=X.device)
+    own = part is None
+    if own:
+        part = wgrad_partials(T, K, M, X.device)[0]
     stream = L.stream_and_check(W, X, Y, out, part, contiguous=False)
     a = L.ProjArgs(L.ptr(W), L.ptr(X), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0), None, 0, None, 0,
                    L.ptr(Y), Y.stride(0), L.ptr(part))
     L.check(lib.cad_proj_wx_wgrad(C.byref(a), stream), "cad_proj_wx_wgrad")
-    return out, part.sum(dim=0)
+    return out, (part.sum(dim=0) if own else None)
 
 
 def proj_wgrad_only_supported(X: torch.Tensor, M: int, K: int, T: int) -> bool:
     return X.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_wgrad_only_supported(int(M), int(K), int(T)))
 
 
-def proj_wgrad_only(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+def proj_wgrad_only(X: torch.Tensor, Y: torch.Tensor, part: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """dW (M, K) fp32 = Y (M, T) @ X (K, T)^T, both channel-major bf16, M <= 64: the weight-gradient stage of cad_proj_wx_wgrad
-    alone (W == NULL) -- dW_x = d(dbc) . xc^T of the x_proj backward."""
+    alone (W == NULL) -- dW_x = d(dbc) . xc^T of the x_proj backward.  part: as for proj_wx_wgrad (slots hold the (K, M) transpose)."""
     K, T = X.shape
     M = Y.shape[0]
     if Y.shape[1] != T or X.stride(1) != 1 or Y.stride(1) != 1:
         raise ValueError("proj_wgrad_only: X (K, T), Y (M, T) with unit inner stride")
     lib = L.get_lib()
-    part = torch.empty((lib.cad_proj_wx_wgrad_partials(T), K, M), dtype=torch.float32, device=X.device)
+    own = part is None
+    if own:
+        part = wgrad_partials(T, K, M, X.device)[0]
     stream = L.stream_and_check(X, Y, part, contiguous=False)
     a = L.ProjArgs(None, L.ptr(X), None, T, M, K, 0, X.stride(0), 0, None, 0, None, 0, L.ptr(Y), Y.stride(0), L.ptr(part))
     L.check(lib.cad_proj_wx_wgrad(C.byref(a), stream), "cad_proj_wx_wgrad")
-    return part.permute(0, 2, 1).sum(dim=0)
+    return part.permute(0, 2, 1).sum(dim=0) if own else None

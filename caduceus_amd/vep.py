@@ -6,7 +6,7 @@ last hidden states over a 1536-bp window centred on the variant (clamped at the 
 reverse-complement strand (the second channel half flipped back for RCPS models, a second forward on the RC input
 otherwise) and stores `concat_avg_ws = [ref | alt]` and `rc_concat_avg_ws`.  Work is sharded over ranks exactly like
 `DistributedSampler(shuffle=False, drop_last=True)` + `DataLoader(drop_last=True)`.
-Differences by design: bf16 autocast instead of fp16, and the four forwards of a Ph model / two of an
+Differences by design: bf16 autocast by default (float16 is accepted and computed in fp32), and the four forwards of a Ph model / two of an
 RCPS model are batched into one launch sequence per step.
 """
 from __future__ import annotations

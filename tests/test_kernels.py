@@ -225,11 +225,13 @@ def test_embed(backend, n_strands):
 
 @pytest.mark.parametrize("n_strands", [1, 2])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_lm_head_and_loss(backend, n_strands, dtype):
+@pytest.mark.parametrize("V,D,B,L", [(16, 40, 2, 300), (16, 256, 2, 301), (12, 128, 1, 75), (16, 256, 1, 9000)])
+def test_lm_head_and_loss(backend, n_strands, dtype, V, D, B, L):
+    """D = 40: the general kernel; D = 128 / 256: the matrix-core kernel (fp32 MFMA, 16-token tiles -- ragged last tile, a vocabulary
+    smaller than the tile, enough tiles for several per wave)."""
     name, dev = backend
     g = torch.Generator().manual_seed(2)
-    V, D, B, L = 16, 40, 2, 300
-    comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15])
+    comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15])[:V]
     W = torch.randn(V, D, generator=g)
     h = torch.randn(n_strands, B, L, D, generator=g).to(dtype).float()
     labels = torch.randint(0, V, (B, L), generator=g)
@@ -362,11 +364,12 @@ def test_scan_gate_exact_zero(backend, dtype):
                                atol=tol["atol"] * max(1.0, float(z.grad[zero].abs().max())))
 
 
-def test_lm_head_loss_is_deterministic(backend):
-    """The fused loss is a two-stage fixed-order sum: repeated runs give identical bits."""
+@pytest.mark.parametrize("D", [32, 256])
+def test_lm_head_loss_is_deterministic(backend, D):
+    """The fused loss is a two-stage fixed-order sum: repeated runs give identical bits (general and matrix-core kernel)."""
     name, dev = backend
     g = torch.Generator().manual_seed(3)
-    S, B, L, D, V = 2, 2, 700, 32, 16
+    S, B, L, V = 2, 2, 700, 16
     hidden = torch.randn(S, B, L, D, generator=g).to(dev)
     w = torch.randn(V, D, generator=g).to(dev)
     comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15]).to(dev)

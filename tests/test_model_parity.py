@@ -60,6 +60,30 @@ def test_layer_trace_matches_reference(backend, name):
         torch.testing.assert_close(residual.cpu(), rec[f"trace/{i}/residual"], **FP32)
 
 
+@pytest.mark.parametrize("name", ["ps_fused", "ph_fused", "ps_unfused"])
+def test_model_fp16_autocast(backend, name):
+    """float16 autocast -- the reference's own AMP precision (configs/experiment/hg38/hg38.yaml:20, vep_embeddings.py:352) -- is
+    served by the fp32 kernels: logits, loss and gradients equal the fp32 run, the hidden states come back as float16."""
+    _, dev = backend
+    model, cfg, sd, rec = build_model(name, dev)
+    ids, labels = rec["input_ids"].to(dev), rec["labels"].to(dev)
+    with torch.autocast(dev.type, dtype=torch.float16):
+        out = model(ids, labels=labels, output_hidden_states=True)
+        hs = model.caduceus(ids).last_hidden_state
+    assert out.logits.dtype == torch.float32 and hs.dtype == torch.float16
+    assert all(h.dtype == torch.float16 for h in out.hidden_states)
+    torch.testing.assert_close(out.logits.cpu(), rec["logits"], **FP32)
+    torch.testing.assert_close(out.loss.cpu(), rec["loss"], **FP32)
+    out.loss.backward()
+    key = ("caduceus.backbone.layers.0.mixer.submodule.mamba_fwd.x_proj.weight" if cfg["rcps"]
+           else "caduceus.backbone.layers.0.mixer.mamba_fwd.x_proj.weight")
+    g = model.state_dict(keep_vars=True)[key].grad
+    torch.testing.assert_close(g.cpu(), rec["grad/" + key], rtol=2e-3, atol=2e-5 * max(1.0, float(rec["grad/" + key].abs().max())))
+    with torch.no_grad():
+        ref_h = model.caduceus(ids).last_hidden_state
+    torch.testing.assert_close(hs.float().cpu(), ref_h.float().cpu(), rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("name", ["ps_fused", "ph_fused", "ps_fused_res32_odd"])
 def test_model_bf16_autocast(backend, name):
     """bf16 compute (autocast, fp32 master weights) against the fp32 reference vectors at the reference's bf16 tolerance."""

@@ -162,3 +162,35 @@ def test_proj_wgrad_only(backend, M, K, T):
     ref = Y.double() @ X.double().t()
     assert dW.shape == (M, K) and dW.dtype == torch.float32
     torch.testing.assert_close(dW.cpu().double(), ref, rtol=1e-4, atol=1e-3 * (T / 128) ** 0.5)
+
+
+def test_mixer_layer_own_wgrad_kernels_match_the_library_path(backend, monkeypatch):
+    """One BiMamba mixer layer (d_model 256: E = 512, dt_rank 16, T = 256 tokens), bf16, forward + backward with dW_dt / dW_x from the
+    own kernels (partial slots of both parameter sets folded by one sum) against the GEMM-library path: same gradients."""
+    from caduceus_amd import mixer
+    from caduceus_amd.mamba import Mamba
+    name, dev = backend
+    torch.manual_seed(0)
+    mf, mr = Mamba(256, device=dev), Mamba(256, device=dev)
+    mr.in_proj.weight = mf.in_proj.weight
+    mr.out_proj.weight = mf.out_proj.weight
+    hn = torch.randn(2, 1, 128, 256, device=dev).to(torch.bfloat16)
+    g = torch.randn(2, 1, 128, 256, device=dev).to(torch.bfloat16)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(mixer, "_FUSED_WGRAD", on)
+        monkeypatch.setattr(mixer, "_OWN_DWX", on)
+        for p in list(mf.parameters()) + list(mr.parameters()):
+            p.grad = None
+        x = hn.clone().requires_grad_(True)
+        mixer.prepare_step_cache([(mf, mr)], torch.bfloat16)
+        out = mixer.bimamba_mixer(x, mf, mr, 1)
+        out.backward(g)
+        res[on] = {n: p.grad.detach().float().cpu().clone() for m, tag in ((mf, "f"), (mr, "r"))
+                   for n, p in ((tag + "." + k, v) for k, v in m.named_parameters())}
+        res[on]["x"] = x.grad.float().cpu()
+    assert ops.proj_wx_wgrad_supported(hn, 16, 512, 256) and ops.proj_wgrad_only_supported(hn, 48, 512, 256)
+    for k in res[True]:
+        a, b = res[True][k], res[False][k]
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-20))
+        assert rel < (2e-2 if ("x_proj" in k or "dt_proj.weight" in k) else 1e-2), (k, rel)
