@@ -138,24 +138,48 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
     if not pairs:
         return
     src, dst, alog, owners = [], [], [], []
-    for mf, mr in pairs:
-        ps = [mf.in_proj.weight, mf.out_proj.weight, mf.x_proj.weight, mf.dt_proj.weight, mr.x_proj.weight,
-              mr.dt_proj.weight]
-        out = [torch.empty(p.shape, dtype=act, device=p.device) for p in ps]
+    # the compute-dtype copies of one kind of weight (in / out / x / dt) of ALL layers are slices of one stacked buffer, so that the
+    # backward's transposed operands (W_out^T, W_x^T, W_dt^T) come from ONE batched transpose per kind and step instead of five
+    # strided copy launches per layer (a multi-tensor copy from transposed views falls back to one launch per tensor)
+    kinds = ("in", "out", "x", "dt")
+    plist = [{"in": [mf.in_proj.weight], "out": [mf.out_proj.weight], "x": [mf.x_proj.weight, mr.x_proj.weight],
+              "dt": [mf.dt_proj.weight, mr.dt_proj.weight]} for mf, mr in pairs]
+    stacked = {}
+    for kd in kinds:
+        shapes = {tuple(p.shape) for pl in plist for p in pl[kd]}
+        n = sum(len(pl[kd]) for pl in plist)
+        if len(shapes) == 1:
+            stacked[kd] = torch.empty((n,) + next(iter(shapes)), dtype=act, device=plist[0][kd][0].device)
+    cursor = {kd: 0 for kd in kinds}
+
+    def alloc(kd, p):
+        if kd in stacked:
+            v = stacked[kd][cursor[kd]]
+            cursor[kd] += 1
+            return v
+        return torch.empty(p.shape, dtype=act, device=p.device)
+
+    for (mf, mr), pl in zip(pairs, plist):
+        ps = [pl["in"][0], pl["out"][0], pl["x"][0], pl["dt"][0], pl["x"][1], pl["dt"][1]]
+        out = [alloc(kd, p) for kd, p in zip(("in", "out", "x", "dt", "x", "dt"), ps)]
         src += [p.detach() for p in ps]
         dst += out
         alog += [mf.A_log.detach().float(), mr.A_log.detach().float()]
         owners.append((mf, ps + [mf.A_log, mr.A_log], out))
-    # the backward's transposed operands (W_out^T, W_dt^T, W_x^T per set) are made here too, once per step, instead of three
-    # `.t().contiguous()` launches per layer and backward
-    src_t, dst_t = [], []
-    for mf, ps, out in owners:
-        tr = [torch.empty((p.shape[1], p.shape[0]), dtype=act, device=p.device) for p in (ps[1], ps[2], ps[3], ps[4], ps[5])]
-        src_t += [p.detach().t() for p in (ps[1], ps[2], ps[3], ps[4], ps[5])]
-        dst_t += tr
-        out.append(tr)
     torch._foreach_copy_(dst, src)
-    torch._foreach_copy_(dst_t, src_t)
+    trans = {kd: stacked[kd].transpose(1, 2).contiguous() for kd in ("out", "x", "dt") if kd in stacked}
+    cursor = {kd: 0 for kd in kinds}
+
+    def transposed(kd, w):
+        if kd in trans:
+            v = trans[kd][cursor[kd]]
+            cursor[kd] += 1
+            return v
+        return w.t().contiguous()
+
+    for mf, ps, out in owners:
+        # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T], in the order the stacked buffers were filled
+        out.append([transposed(kd, out[j]) for kd, j in (("out", 1), ("x", 2), ("dt", 3), ("x", 4), ("dt", 5))])
     negA = torch._foreach_exp(alog)
     torch._foreach_neg_(negA)
     for i, (mf, ps, out) in enumerate(owners):
@@ -364,7 +388,9 @@ class BiMambaMixerFn(torch.autograd.Function):
                             bufs=[(zbuf[5 * i + 3], zbuf[5 * i + 4] if sets[i][7] is not None else None) for i in range(2)])
         # one fold per weight for BOTH sets' partial slots (fixed order): (2, P, K, M) -> (2, K, M) / (2, M, K)
         sum_dt = None if wg_dt is None else wg_dt.sum(dim=1)
-        sum_x = None if wg_x is None else wg_x.permute(0, 1, 3, 2).sum(dim=1)
+        # (the slots hold (K, M); summed as they lie -- a reduction over a permuted view runs at a quarter of the rate -- and the
+        # small (2, K, M) result is transposed)
+        sum_x = None if wg_x is None else wg_x.sum(dim=1).transpose(1, 2).contiguous()
         for i in range(2):
             meta = pmeta[i]
             (dwc, dbc_conv), (dW_x, dW_dt, dbias, dA_log, dD) = conv_g[i], part[i]

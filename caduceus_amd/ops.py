@@ -661,4 +661,4 @@ def proj_wgrad_only(X: torch.Tensor, Y: torch.Tensor, part: Optional[torch.Tenso
     stream = L.stream_and_check(X, Y, part, contiguous=False)
     a = L.ProjArgs(None, L.ptr(X), None, T, M, K, 0, X.stride(0), 0, None, 0, None, 0, L.ptr(Y), Y.stride(0), L.ptr(part))
     L.check(lib.cad_proj_wx_wgrad(C.byref(a), stream), "cad_proj_wx_wgrad")
-    return part.permute(0, 2, 1).sum(dim=0) if own else None
+    return part.sum(dim=0).t().contiguous() if own else None
