@@ -32,13 +32,22 @@ int cad_after_launch() { return hipGetLastError() == hipSuccess ? CAD_OK : CAD_E
 
 namespace {
 std::mutex g_mu;
-bool g_on = false;
+unsigned g_mask = 0;  // bit k: kind k is timed
 #ifndef CAD_EMU
 struct Rec {
     int kind;
     hipEvent_t a, b;
 };
 std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_free;  // events of earlier measurements, reused: no hipEventCreate on the launch path after the first pass
+bool take_event(hipEvent_t* e) {
+    if (!g_free.empty()) {
+        *e = g_free.back();
+        g_free.pop_back();
+        return true;
+    }
+    return hipEventCreate(e) == hipSuccess;
+}
 #else
 int64_t g_counts[CAD_PROF_KINDS];
 #endif
@@ -46,11 +55,15 @@ int64_t g_counts[CAD_PROF_KINDS];
 
 CadProfScope::CadProfScope(int k, void* s) : kind(k), stream(s), slot(-1) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_on) return;
+    if (!((g_mask >> k) & 1u)) return;
 #ifndef CAD_EMU
     Rec r;
     r.kind = k;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    if (!take_event(&r.a)) return;
+    if (!take_event(&r.b)) {
+        g_free.push_back(r.a);
+        return;
+    }
     (void)hipEventRecord(r.a, (hipStream_t)s);
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
@@ -68,16 +81,22 @@ CadProfScope::~CadProfScope() {
 
 extern "C" int cad_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_on = on != 0;
+    g_mask = on ? ~0u : 0u;
+    return CAD_OK;
+}
+
+extern "C" int cad_prof_enable_kinds(unsigned mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_mask = mask;
     return CAD_OK;
 }
 
 extern "C" int cad_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
 #ifndef CAD_EMU
-    for (auto& r : g_recs) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+    for (auto& r : g_recs) {  // (the caller has synchronised: cad_prof_read, or the stream)
+        g_free.push_back(r.a);
+        g_free.push_back(r.b);
     }
     g_recs.clear();
 #else

@@ -583,18 +583,23 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     }
 }
 
-// Gate gradient where z == 0 exactly (see the worklist in scan_bwd_kernel): one wave per recorded (channel, row, chunk)
+// Gate gradient where z == 0 exactly (see the worklist in scan_bwd_kernel): one WORKGROUP per recorded (channel, row, chunk)
 // recomputes the UNGATED y of that chunk from the saved chunk state (serial scan + DPP wave scan, as the forward) and
 // adds  dout * y * sigmoid(0) = dout * y / 2  to dz at the positions whose gate is 0.  Rare path: element-wise loads.
+// (Rare per element, not per launch: 134 M gate values per configs[2] launch and P(an fp32 sum rounds to 0) ~ 4e-9 make about one
+// entry per two launches.)  The four waves share the state pairs -- the path is a chain of dependent global round trips, one per
+// state pair -- and their partial y are added in a fixed order through LDS.
+#define GF_WAVES 4
 template <typename T>
-__global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a) {
+__global__ __launch_bounds__(64 * GF_WAVES) void scan_gate_fix_kernel(cad_scan_bwd_args a) {
+    __shared__ float ypart[GF_WAVES - 1][SC_S][64];
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
     const int count = *a.gate_fix_count;
     const int64_t L = a.L, SB = a.SB;
     const int N = a.N, NP = (N + 1) >> 1;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
-    for (int idx = blockIdx.x * 4 + wave; idx < count; idx += gridDim.x * 4) {
+    for (int idx = blockIdx.x; idx < count; idx += gridDim.x) {  // (count is uniform: every wave makes the same trips)
         const int64_t ent = a.gate_fix_list[idx];
         const int e = (int)(ent & 0xFFFFF);
         const int64_t sb = (ent >> 20) & 0xFFFFF, c = ent >> 40;
@@ -618,10 +623,10 @@ __global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a)
             const float ui = ok ? to_f32(u_row[l]) : 0.f;
             const float draw = to_f32(d_row[l]) + bias;
             const float dti = ok ? (is_dt ? draw : cad_softplus(draw)) : 0.f;
-            y[i] = Dv * ui;
+            y[i] = wave == 0 ? Dv * ui : 0.f;
             dd[i] = f2(dti, dti * ui);
         }
-        for (int np = 0; np < NP; ++np) {
+        for (int np = wave; np < NP; np += GF_WAVES) {
             const int n0 = 2 * np;
             const bool two = n0 + 1 < N;
             const f32x2 A2 = f2(a.A[e * N + n0], two ? a.A[e * N + n0 + 1] : 0.f) * f2(CAD_LOG2E);
@@ -653,14 +658,24 @@ __global__ __launch_bounds__(256) void scan_gate_fix_kernel(cad_scan_bwd_args a)
                 y[i] += dot2(Cv[i], h);
             }
         }
+        if (wave > 0) {
 #pragma unroll
-        for (int i = 0; i < SC_S; ++i) {
-            if (p0 + i < L) {
-                const int64_t l = cad_phys(p0 + i, L, rev);
-                if (to_f32(z_row[l]) == 0.f)
-                    dz_row[l] = from_f32<T>(to_f32(dz_row[l]) + 0.5f * to_f32(g_row[l]) * y[i]);
+            for (int i = 0; i < SC_S; ++i) ypart[wave - 1][i][lane] = y[i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+#pragma unroll
+                for (int w = 0; w < GF_WAVES - 1; ++w) y[i] += ypart[w][i][lane];
+                if (p0 + i < L) {
+                    const int64_t l = cad_phys(p0 + i, L, rev);
+                    if (to_f32(z_row[l]) == 0.f)
+                        dz_row[l] = from_f32<T>(to_f32(dz_row[l]) + 0.5f * to_f32(g_row[l]) * y[i]);
+                }
             }
         }
+        __syncthreads();  // ypart is reused by the next entry
     }
 }
 
@@ -786,7 +801,7 @@ extern "C" int cad_scan_bwd_gate_fix(const cad_scan_bwd_args* sets, int nsets, v
         if (!a->gate_fix_list) continue;
         CAD_CHECK_ARG(a->gate_fix_count && a->gate_fix_dz && a->z && a->chunk_state);
         CAD_CHECK_ARG(a->E <= (1 << 20) && a->SB <= (1 << 20));
-        dim3 grid(32), block(256);  // almost always an empty worklist: keep the dispatch itself small
+        dim3 grid(32), block(64 * GF_WAVES);  // an empty or one-entry worklist as a rule: keep the dispatch itself small
         if (a->dtype == CAD_F32)
             CAD_LAUNCH((scan_gate_fix_kernel<float>), grid, block, 0, stream, *a);
         else if (a->dtype == CAD_BF16)

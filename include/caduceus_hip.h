@@ -432,7 +432,10 @@ int cad_fasta_fetch(void* handle, int64_t seq, int64_t start, int64_t end, uint8
  * Opt-in kernel timer (HIP events on the launch stream) used by bench.py for the roofline line.
  * kind: 0 scan_fwd, 1 scan_bwd, 2 conv_fwd, 3 conv_bwd, 4 add_norm_fwd, 5 add_norm_bwd, 6 embed, 7 lm_head, 8 proj. */
 #define CAD_PROF_KINDS 9
-int cad_prof_enable(int on);
+int cad_prof_enable(int on);                  /* all kinds */
+/* Only the kinds whose bit is set (bit k = kind k).  Every timed launch costs two event records on its stream (~10 us of idle queue
+ * per launch in the kernel trace: 5 % of a training step with all kinds on); bench.py times the two scan kinds in its timed region. */
+int cad_prof_enable_kinds(unsigned mask);
 int cad_prof_reset(void);
 /* Synchronises the recorded events.  Outputs total milliseconds and number of launches of that kind. */
 int cad_prof_read(int kind, double* total_ms, int64_t* launches);

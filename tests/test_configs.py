@@ -318,3 +318,41 @@ def test_ph_L131072_lsplit_training_step_matches_unsplit(monkeypatch):
     for k in ga:
         e = float((ga[k].float() - gb[k].float()).norm() / gb[k].float().norm().clamp_min(1e-12))
         assert e < 2e-2, (k, e)
+
+
+def test_config2_lm_head_L131072_matrix_core_kernel():
+    """The LM head of configs[2] at its full size (2 strands x 131072 tokens x 256 channels, vocabulary 16) on the fp32 matrix-core
+    kernel: logits and the masked cross entropy against the plain fp32 product of the same bf16 hidden states, and the RCPS property
+    at full size -- exchanging the strands gives the complement-permuted logits BIT FOR BIT."""
+    from caduceus_amd import ops
+    g = torch.Generator().manual_seed(9)
+    S, B, L, D, V = 2, 1, 131072, 256, 16
+    h = torch.randn(S, B, L, D, generator=g).to(torch.bfloat16).to(DEV)
+    w = (0.05 * torch.randn(V, D, generator=g)).to(DEV)
+    comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15], device=DEV)
+    labels = torch.randint(0, V, (B, L), generator=g)
+    labels[torch.rand(B, L, generator=g) > 0.15] = 4
+    labels = labels.to(DEV)
+    logits, loss = ops.lm_head(h, w, comp, labels, 4)
+    ref = h[0].float() @ w.t() + h[1].float() @ w[comp].t()
+    torch.testing.assert_close(logits, ref, rtol=1e-5, atol=2e-5)
+    ref_loss = F.cross_entropy(ref.reshape(-1, V).double(), labels.reshape(-1), ignore_index=4)
+    torch.testing.assert_close(loss.double(), ref_loss, rtol=1e-5, atol=1e-6)
+    swapped, _ = ops.lm_head(torch.stack([h[1], h[0]]), w, comp, None, 4)
+    assert torch.equal(swapped[..., comp], logits)
+
+
+def test_config2_fp16_autocast_request_on_the_device():
+    """float16 autocast (the reference's trainer.precision=16 and vep_embeddings.py:352) at the configs[2] layer shape, two layers:
+    computed by the fp32 kernels -- logits equal the fp32 run, hidden states are float16."""
+    from caduceus_amd import CaduceusForMaskedLM
+    import bench
+    torch.manual_seed(0)
+    model = CaduceusForMaskedLM(bench.make_config(256, 2)).to(DEV).eval()
+    ids, _ = bench.synthetic_batch(torch.Generator().manual_seed(3), 1, 16384, torch.device(DEV))
+    with torch.no_grad():
+        ref = model(ids).logits
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = model(ids, output_hidden_states=True)
+    assert out.logits.dtype == torch.float32 and all(hs.dtype == torch.float16 for hs in out.hidden_states)
+    torch.testing.assert_close(out.logits, ref, rtol=1e-5, atol=1e-5)

@@ -15,10 +15,12 @@ import csv, glob
 f = glob.glob("gpurun_out/prof_step/trace/**/*kernel_stats.csv", recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
+    NS = 4  # bench.py --steps 2 --warmup 1 + its one extra untimed step (all kernel families timed)
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    out = [f"total kernel time per step: {tot / 3e6:.1f} ms (3 steps traced incl. warm-up)"]
+    out = [f"total kernel time per step: {tot / NS / 1e6:.1f} ms ({NS} steps traced incl. warm-up and the extra instrumented step; "
+           "model initialisation is in the totals: fills, normal_)"]
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
-        out.append(f"{float(r['TotalDurationNs']) / 3e6:8.2f} ms/step {float(r['Percentage']):6.2f}% calls/step={int(r['Calls']) / 3:7.1f} avg_us={float(r['AverageNs']) / 1e3:9.1f}  {r['Name'][:150]}")
+        out.append(f"{float(r['TotalDurationNs']) / NS / 1e6:8.2f} ms/step {float(r['Percentage']):6.2f}% calls/step={int(r['Calls']) / NS:7.1f} avg_us={float(r['AverageNs']) / 1e3:9.1f}  {r['Name'][:150]}")
     open("gpurun_out/step_trace_final.txt", "w").write("\n".join(out) + "\n")
     print("\n".join(out[:14]))
 PY
