@@ -394,13 +394,6 @@ __device__ __forceinline__ void cad_sched_fence() {
 #endif
 }
 
-// scheduling fence: nothing is moved across this point by the instruction scheduler (device build)
-__device__ __forceinline__ void cad_sched_group_fence() {
-#ifndef CAD_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
 // ---- direction / index maps ----------------------------------------------------------------------------------
 // logical position p in [0, L) of a row <-> physical index along L
 __device__ __forceinline__ int64_t cad_phys(int64_t p, int64_t L, int rev) { return rev ? (L - 1 - p) : p; }

@@ -400,9 +400,9 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
     const int64_t total = nmine * NCH;               // (block, chunk) iterations of this workgroup
     char* wl = smem + C::RING * C::XBUF;             // W copy: row stride WSTR (padded: the 16 rows of a B fragment read spread over the banks)
     const int WSTR = K * 2 + 16;
-    // the (block, chunk) position of the next chunk to issue and of the chunk being consumed are carried as counters: a 64-bit
-    // division by the run-time NCH per chunk (scalar long division, ~150 instructions, twice per iteration between the barrier
-    // and the next DMA issue) made this kernel 1.5x slower than the weight-gradient kernel below on the same operand
+    // the (block, chunk) position of the next chunk to issue and of the chunk being consumed are carried as counters (no 64-bit
+    // division by the run-time NCH between the barrier and the next DMA issue; time-neutral when measured: this kernel's 88 us in the
+    // step against 56 us in a loop is the memory-side cache, profiles/r03_ab_conv_addnorm.txt (3))
     int ich = 0, islot = 0;
     int64_t iblk = b0;
     auto issue_next = [&]() {
