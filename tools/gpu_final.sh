@@ -24,4 +24,5 @@ if f:
     open("gpurun_out/step_trace_final.txt", "w").write("\n".join(out) + "\n")
     print("\n".join(out[:14]))
 PY
+cp gpurun_out/scan_pmc.json profiles/r03_scan_pmc.json  # (on the box: the bench line below quotes the counters taken on THIS build)
 timeout 400 python bench.py > gpurun_out/bench_final.log 2>gpurun_out/bench_final.err; tail -1 gpurun_out/bench_final.log | cut -c1-400
