@@ -101,6 +101,12 @@ class LmHeadArgs(C.Structure):
                 ("dtype", _i), ("block_partials", _p)]
 
 
+class LmHeadBwdArgs(C.Structure):
+    _fields_ = [("hidden", _p), ("weight", _p), ("comp", _p), ("labels", _p), ("logits", _p), ("dlogits", _p),
+                ("loss_scale", _p), ("dhidden", _p), ("dw_partials", _p), ("rows", _i64), ("D", _i), ("V", _i),
+                ("n_strands", _i), ("ignore_index", _i64), ("dtype", _i)]
+
+
 # every exported symbol of include/caduceus_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "cad_version": (C.c_char_p, []),
@@ -138,6 +144,9 @@ SYMBOLS = {
     "cad_proj_fp8_supported": (_i, [_i]),
     "cad_lm_head_fwd": (_i, [C.POINTER(LmHeadArgs), _p]),
     "cad_lm_head_partials": (_i64, [_i64]),
+    "cad_lm_head_bwd": (_i, [C.POINTER(LmHeadBwdArgs), _p]),
+    "cad_lm_head_bwd_supported": (_i, [_i, _i]),
+    "cad_lm_head_bwd_partials": (_i64, [_i64]),
     "cad_tokenize_mlm": (_i, [C.POINTER(MlmArgs), _p]),
     "cad_mlm_threshold": (C.c_uint32, [C.c_double]),
     "cad_hg38_interval": (_i, [_i64, _i64, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),

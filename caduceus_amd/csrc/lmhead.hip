@@ -230,6 +230,161 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_fwd_mfma_kernel(cad_lm_
     }
 }
 
+// Backward on the matrix cores (D = 16 NCB, NCB in {8, 16}), one 16-token tile per wave at a time, v_mfma_f32_16x16x4_f32 throughout.
+// MFMA column / row index j of channel block cb stands for channel  j * NCB + cb : a lane then owns NCB CONTIGUOUS channels of a
+// token (or of a weight row) across the NCB blocks -- hidden rows, weight rows, d hidden rows and the dW slot are all moved with
+// 16-byte accesses.
+//   G tile (the loss gradient w.r.t. the logits) in the layout of the forward's epilogue (lane = vocabulary column, 4 token rows),
+//   softmax over the 16 lanes of a row; it goes through a wave-private LDS tile, from which both products take their fragments:
+//   d hidden^T block cb = sum_m  W^T[channels of cb][v = 4m + k]  .  G^T[v = 4m + k][tokens]          (4 MFMAs per block and strand)
+//   dW block cb        += sum_m  G^T[v][tokens 4m + k]            .  hidden[tokens 4m + k][channels of cb]
+//   strand 1 reads the G tile with its columns permuted by comp (the same W registers and accumulators serve both strands).
+// Each wave keeps dW (16 x D fp32) in NCB accumulator tiles; the four waves' tiles are added through LDS, one slot per workgroup.
+template <typename T, int NCB>
+__global__ __launch_bounds__(64 * LM_WAVES) void lm_head_bwd_mfma_kernel(cad_lm_head_bwd_args a) {
+    constexpr int D = 16 * NCB;
+    constexpr int GS = 17;  // row stride of the G tile (floats)
+    __shared__ float gs_all[LM_WAVES][16 * GS];
+    __shared__ float fold[LM_WAVES - 1][NCB][64 * 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, jl = lane & 15;
+    const int V = a.V;
+    const T* hid = (const T*)a.hidden;
+    T* dh = (T*)a.dhidden;
+    const int64_t rows = a.rows;
+    const int64_t ntiles = (rows + 15) / 16;
+    float* gs = gs_all[wave];
+    const float coef = a.loss_scale ? a.loss_scale[0] : 0.f;
+    // A fragments of d hidden^T: W[v = 4m + g][channel jl * NCB + cb]  (rows v >= V are zero)
+    float wreg[4][NCB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) wreg[m][cb] = (4 * m + g) < V ? a.weight[(int64_t)(4 * m + g) * D + jl * NCB + cb] : 0.f;
+    int cperm[4];  // strand 1: column comp[4m + g] of the G tile feeds k = 4m + g
+#pragma unroll
+    for (int m = 0; m < 4; ++m) cperm[m] = (a.n_strands == 2 && 4 * m + g < V) ? (int)a.comp[4 * m + g] : 4 * m + g;
+    const int cjl = (a.n_strands == 2 && jl < V) ? (int)a.comp[jl] : jl;
+    f32x4 dw[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) dw[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int EPV = 16 / sizeof(T);       // elements per 16-byte access
+    constexpr int NV = NCB / EPV;             // 16-byte accesses per lane and token row segment
+    struct __attribute__((aligned(16))) Raw { uint32_t w[4]; };
+    for (int64_t tile = (int64_t)blockIdx.x * LM_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * LM_WAVES) {
+        // ---- G tile: lane (column jl, rows 4 g + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = tile * 16 + 4 * g + r;
+            const bool ok = row < rows;
+            float gv = 0.f;
+            if (a.labels) {
+                const float z = (ok && jl < V) ? a.logits[row * V + jl] : -3.0e38f;
+                float mx = z;
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) {
+                    const float o = __shfl_xor(mx, m);
+                    mx = o > mx ? o : mx;
+                }
+                const float e = (ok && jl < V) ? expf(z - mx) : 0.f;
+                float se = e;
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) se += __shfl_xor(se, m);
+                const int64_t lab = ok ? a.labels[row] : a.ignore_index;
+                const bool counts = lab != a.ignore_index && lab >= 0 && lab < V;
+                if (counts && jl < V) gv = (e / se - ((int64_t)jl == lab ? 1.f : 0.f)) * coef;
+            }
+            if (a.dlogits && ok && jl < V) gv += a.dlogits[row * V + jl];
+            gs[(4 * g + r) * GS + jl] = gv;
+        }
+        cad_wave_sync();
+        for (int s = 0; s < a.n_strands; ++s) {
+            int64_t trow = tile * 16 + jl;
+            const bool tok = trow < rows;
+            trow = tok ? trow : rows - 1;
+            // ---- d hidden: B fragments G_s[token jl][v = 4m + g]
+            float bg[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bg[m] = gs[jl * GS + (s == 0 ? 4 * m + g : cperm[m])];
+            f32x4 z[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                z[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) z[cb] = cad_mfma_16x16x4_f32(wreg[m][cb], bg[m], z[cb]);
+            }
+            // lane (token jl, rows 4 g + r): channels (4 g + r) * NCB .. + NCB - 1
+            if (tok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T* dst = dh + ((int64_t)s * rows + trow) * D + (4 * g + r) * NCB;
+#pragma unroll
+                    for (int q = 0; q < NCB; q += 4) {
+                        const float v4[4] = {z[q][r], z[q + 1][r], z[q + 2][r], z[q + 3][r]};
+                        cad_cvt_store<T, 4>(dst + q, v4);
+                    }
+                }
+            }
+            // ---- dW: A fragments G_s[token 4m + g][v' = jl], B fragments hidden[token 4m + g][channels jl * NCB .. + NCB - 1]
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float ag = gs[(4 * m + g) * GS + (s == 0 ? jl : cjl)];
+                int64_t hrow = tile * 16 + 4 * m + g;
+                const bool hok = hrow < rows;
+                hrow = hok ? hrow : rows - 1;
+                const T* src = hid + ((int64_t)s * rows + hrow) * D + jl * NCB;
+                float hv[NCB];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const Raw rw = *(const Raw*)(src + q * EPV);
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hv[q * 8 + 2 * e] = cad_bits2f(rw.w[e] << 16);
+                            hv[q * 8 + 2 * e + 1] = cad_bits2f(rw.w[e] & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[q * 4 + e] = cad_bits2f(rw.w[e]);
+                    }
+                }
+                const float agm = hok ? ag : 0.f;  // rows beyond the end add nothing
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) dw[cb] = cad_mfma_16x16x4_f32(agm, hv[cb], dw[cb]);
+            }
+        }
+        cad_wave_sync();  // the G tile is rewritten by the next tile
+    }
+    // the four waves' dW tiles -> one slot per workgroup (fixed order); lane (column jl, rows v = 4 g + r): channels jl * NCB + cb
+    if (wave > 0) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) *(f32x4*)(&fold[wave - 1][cb][lane * 4]) = dw[cb];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int w = 0; w < LM_WAVES - 1; ++w) {
+                const f32x4 o = *(const f32x4*)(&fold[w][cb][lane * 4]);
+                dw[cb][0] += o[0], dw[cb][1] += o[1], dw[cb][2] += o[2], dw[cb][3] += o[3];
+            }
+        float* slot = a.dw_partials + (int64_t)blockIdx.x * V * D;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = 4 * g + r;
+            if (v < V) {
+#pragma unroll
+                for (int q = 0; q < NCB; q += 4) {
+                    const float v4[4] = {dw[q][r], dw[q + 1][r], dw[q + 2][r], dw[q + 3][r]};
+                    cad_cvt_store<float, 4>(slot + (int64_t)v * D + jl * NCB + q, v4);
+                }
+            }
+        }
+    }
+}
+
 // second stage of the deterministic loss: one workgroup folds the per-workgroup (loss, count) pairs with a fixed-shape
 // tree (the same association order on every run and for every grid of the same size)
 #define LM_FOLD_THREADS 256
@@ -303,5 +458,38 @@ extern "C" int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream) {
     if (a->labels && a->block_partials)
         CAD_LAUNCH(lm_loss_fold_kernel, dim3(1), dim3(LM_FOLD_THREADS), 0, stream, (const float*)a->block_partials, (int)nb,
                    a->loss_sum, a->count);
+    return cad_after_launch();
+}
+
+extern "C" int cad_lm_head_bwd_supported(int D, int V) { return (D == 128 || D == 256) && V >= 1 && V <= LM_VMAX; }
+
+static int64_t lm_head_bwd_blocks(int64_t rows) {
+    int64_t nb = ((rows + 15) / 16 + LM_WAVES - 1) / LM_WAVES;
+    return nb > 512 ? 512 : nb;
+}
+extern "C" int64_t cad_lm_head_bwd_partials(int64_t rows) { return lm_head_bwd_blocks(rows); }
+
+extern "C" int cad_lm_head_bwd(const cad_lm_head_bwd_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->hidden && a->weight && a->dhidden && a->dw_partials);
+    CAD_CHECK_ARG(a->rows > 0 && a->D > 0 && a->V > 0);
+    CAD_CHECK_ARG(a->n_strands == 1 || (a->n_strands == 2 && a->comp));
+    CAD_CHECK_ARG(!a->labels || (a->logits && a->loss_scale));
+    CAD_CHECK_ARG(a->labels || a->dlogits);
+    if (!cad_lm_head_bwd_supported(a->D, a->V) || (a->dtype != CAD_F32 && a->dtype != CAD_BF16)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG((((uintptr_t)a->hidden | (uintptr_t)a->dhidden | (uintptr_t)a->dw_partials) % 16) == 0);
+    CadProfScope prof(7, stream);
+    dim3 grid((unsigned)lm_head_bwd_blocks(a->rows)), block(64 * LM_WAVES);
+#define LM_BWD(NCB_)                                                                              \
+    do {                                                                                          \
+        if (a->dtype == CAD_F32)                                                                  \
+            CAD_LAUNCH((lm_head_bwd_mfma_kernel<float, NCB_>), grid, block, 0, stream, *a);       \
+        else                                                                                      \
+            CAD_LAUNCH((lm_head_bwd_mfma_kernel<bf16_t, NCB_>), grid, block, 0, stream, *a);      \
+    } while (0)
+    if (a->D == 128)
+        LM_BWD(8);
+    else
+        LM_BWD(16);
+#undef LM_BWD
     return cad_after_launch();
 }

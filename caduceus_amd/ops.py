@@ -478,6 +478,22 @@ class _LmHead(torch.autograd.Function):
         ignore_index, wdt, has_labels = ctx.meta
         S, D = hidden.shape[0], hidden.shape[-1]
         V = w.shape[0]
+        lib = L.get_lib()
+        use_loss = has_labels and dloss is not None
+        if (use_loss or dlogits is not None) and hidden.dtype in (torch.float32, torch.bfloat16) and \
+                lib.cad_lm_head_bwd_supported(int(D), int(V)):
+            # one launch on the matrix cores: softmax gradient, d hidden of both strands, dW partial slots (cad_lm_head_bwd)
+            rows = hidden.numel() // (S * D)
+            dh = torch.empty_like(hidden)
+            parts = torch.empty((lib.cad_lm_head_bwd_partials(rows), V, D), dtype=torch.float32, device=hidden.device)
+            coef = (dloss.float() / acc[1]).reshape(1) if use_loss else None
+            dlg = None if dlogits is None else dlogits.reshape(-1, V).float().contiguous()
+            stream = L.stream_and_check(hidden, w, comp, lab if use_loss else None, logits, dlg, coef, dh, parts)
+            a = L.LmHeadBwdArgs(L.ptr(hidden), L.ptr(w), L.ptr(comp), L.ptr(lab) if use_loss else None, L.ptr(logits), L.ptr(dlg),
+                                L.ptr(coef), L.ptr(dh), L.ptr(parts), rows, D, V, S, int(ignore_index), L.dtype_code(hidden.dtype))
+            L.check(lib.cad_lm_head_bwd(C.byref(a), stream), "cad_lm_head_bwd")
+            return dh, parts.sum(dim=0).to(wdt), None, None, None
+        # (other shapes: torch ops)
         # d loss / d logits = (softmax - onehot) * valid / count, assembled WITHOUT boolean-mask indexing: `sm[rows[valid], lab[valid]]`
         # goes through nonzero(), i.e. a device-to-host copy in the middle of the backward -- the launch queue ran dry behind it
         # (~0.4 ms of idle gaps per step in the kernel trace)

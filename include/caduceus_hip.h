@@ -381,6 +381,32 @@ typedef struct {
 int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream);
 int64_t cad_lm_head_partials(int64_t rows);
 
+/* Backward of cad_lm_head_fwd in one launch (replaces the autograd of RCPSLMHead.forward + cross_entropy):
+ *   g[t][v]      = (softmax(logits[t])[v] - [v == labels[t]]) * [labels[t] counts] * loss_scale[0]  (+ dlogits[t][v])
+ *   dhidden[0,t] = sum_v g[t][v] W[v],   dhidden[1,t] = sum_v g[t][v] W[comp[v]]
+ *   dW[v]        = sum_t g[t][v] hidden[0,t] + sum_t g[t][comp[v]] hidden[1,t]      (comp is an involution)
+ * logits as written by the forward; loss_scale = d loss / count on the device (NULL iff labels is NULL); dlogits (rows, V) fp32 or
+ * NULL.  dw_partials: cad_lm_head_bwd_partials(rows) slots of (V, D) fp32, one per workgroup, WRITTEN (the caller sums them in
+ * order: deterministic).  Shapes: cad_lm_head_bwd_supported (d_model 128 / 256, V <= 16); others return CAD_ERR_UNSUPPORTED. */
+typedef struct {
+    const void* hidden;
+    const float* weight;
+    const int64_t* comp;
+    const int64_t* labels;
+    const float* logits;
+    const float* dlogits;
+    const float* loss_scale;
+    void* dhidden;
+    float* dw_partials;
+    int64_t rows;
+    int D, V, n_strands;
+    int64_t ignore_index;
+    int dtype;
+} cad_lm_head_bwd_args;
+int cad_lm_head_bwd(const cad_lm_head_bwd_args* a, void* stream);
+int cad_lm_head_bwd_supported(int D, int V);
+int64_t cad_lm_head_bwd_partials(int64_t rows);
+
 /* ---------------------------------------------------------------------------------------------------------
  * hg38 data path -- the step in front of the model.
  *

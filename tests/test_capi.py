@@ -61,7 +61,7 @@ def test_ctypes_structs_mirror_header():
               "cad_add_norm_args": _lib.AddNormArgs, "cad_add_norm_bwd_args": _lib.AddNormBwdArgs,
               "cad_conv1d_args": _lib.Conv1dArgs, "cad_conv1d_bwd_args": _lib.Conv1dBwdArgs,
               "cad_scan_args": _lib.ScanArgs, "cad_scan_bwd_args": _lib.ScanBwdArgs,
-              "cad_lm_head_args": _lib.LmHeadArgs, "cad_mlm_args": _lib.MlmArgs,
+              "cad_lm_head_args": _lib.LmHeadArgs, "cad_lm_head_bwd_args": _lib.LmHeadBwdArgs, "cad_mlm_args": _lib.MlmArgs,
               "cad_proj_args": _lib.ProjArgs, "cad_quant_fp8_args": _lib.QuantFp8Args,
               "cad_proj_fp8_args": _lib.ProjFp8Args}
     assert set(hs) == set(mirror)
@@ -82,7 +82,7 @@ def test_struct_sizes_match_compiler(tmp_path):
               "cad_add_norm_args": _lib.AddNormArgs, "cad_add_norm_bwd_args": _lib.AddNormBwdArgs,
               "cad_conv1d_args": _lib.Conv1dArgs, "cad_conv1d_bwd_args": _lib.Conv1dBwdArgs,
               "cad_scan_args": _lib.ScanArgs, "cad_scan_bwd_args": _lib.ScanBwdArgs,
-              "cad_lm_head_args": _lib.LmHeadArgs, "cad_mlm_args": _lib.MlmArgs,
+              "cad_lm_head_args": _lib.LmHeadArgs, "cad_lm_head_bwd_args": _lib.LmHeadBwdArgs, "cad_mlm_args": _lib.MlmArgs,
               "cad_proj_args": _lib.ProjArgs, "cad_quant_fp8_args": _lib.QuantFp8Args,
               "cad_proj_fp8_args": _lib.ProjFp8Args}
     for n, cls in mirror.items():

@@ -204,10 +204,12 @@ def test_add_norm_many_rows(backend, S, R, D, xdt):
 
 
 @pytest.mark.parametrize("n_strands", [1, 2])
-def test_embed(backend, n_strands):
+@pytest.mark.parametrize("D", [48, 256, 50])
+def test_embed(backend, n_strands, D):
+    """D % 4 == 0: the vector kernels (a wave per token, per-wave LDS tables in the backward); D = 50: the scalar kernels."""
     name, dev = backend
     g = torch.Generator().manual_seed(0)
-    V, D, B, L = 16, 48, 3, 700
+    V, B, L = 16, 3, 700
     ids = torch.randint(0, V, (B, L), generator=g)
     comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15])
     W = torch.randn(V, D, generator=g)
@@ -362,6 +364,26 @@ def test_scan_gate_exact_zero(backend, dtype):
                                    msg=lambda m, k=k: f"d{k}: {m}")
     torch.testing.assert_close(ins[6].grad.float().cpu()[zero], z.grad[zero], rtol=tol["rtol"],
                                atol=tol["atol"] * max(1.0, float(z.grad[zero].abs().max())))
+
+
+@pytest.mark.parametrize("D", [40, 128])
+def test_lm_head_backward_without_labels(backend, D):
+    """Only an upstream gradient of the logits (no loss): cad_lm_head_bwd with labels == NULL (D = 128) / the torch path (D = 40)."""
+    name, dev = backend
+    g = torch.Generator().manual_seed(4)
+    S, B, L, V = 2, 1, 333, 16
+    comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15])
+    h, W = torch.randn(S, B, L, D, generator=g), torch.randn(V, D, generator=g)
+    up = torch.randn(B, L, V, generator=g)
+    hd, wd = leaf(h, dev), leaf(W, dev)
+    logits, _ = ops.lm_head(hd, wd, comp.to(dev), None, 4)
+    (logits * up.to(dev)).sum().backward()
+    rh, rw = leaf(h, 'cpu'), leaf(W, 'cpu')
+    rl = F.linear(rh[0], rw) + F.linear(rh[1], rw[comp])
+    (rl * up).sum().backward()
+    torch.testing.assert_close(logits.cpu(), rl.detach(), **FP32)
+    torch.testing.assert_close(hd.grad.cpu(), rh.grad, **FP32)
+    torch.testing.assert_close(wd.grad.cpu(), rw.grad, rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("D", [32, 256])
