@@ -37,7 +37,7 @@ SCAN_CASES = [  # E, SB, L, N, split, rev_lo, rev_hi
     (3, 2, 37, 8, 1, 1, 0),
     (5, 1, 1100, 16, 0, 0, 1),
     (2, 1, 1, 3, 1, 0, 0),
-    (9, 3, 2064, 16, 2, 1, 0),
+    (9, 3, 1040, 16, 2, 1, 0),  # > 8 channels, three rows, forward chunks 1024 + 16, backward chunks 512 + 512 + 16
 ]
 
 
