@@ -155,32 +155,39 @@ struct DirTag {
 template <typename T, int NSETS, bool VEC>
 __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets) {
     const cad_conv1d_args& a0 = sets.s[0];
-    const int64_t rowid = blockIdx.x;  // e * SB + sb
-    const int e = (int)(rowid / a0.SB);
-    const int64_t sb = rowid - (int64_t)e * a0.SB;
-    const int64_t L = a0.L;
+    // A workgroup belongs to ONE channel e and walks "virtual tiles" v = row * tiles_per_row + tile over that channel's rows: long rows
+    // (one sequence per row) behave as before, short rows (L = 1024, 128 rows) no longer leave a wave idle and a workgroup with a
+    // single tile of work per wave (the backward also folds its per-channel sums once per 32 tiles instead of once per row).
+    const int e = blockIdx.x;
+    const int64_t L = a0.L, SB = a0.SB;
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
-    const T* x = (const T*)a0.x + rowid * L;
+    const uint32_t tpr = (uint32_t)((L + CV_WAVE_POS - 1) / CV_WAVE_POS);  // tiles per row
+    const uint32_t nvt = (uint32_t)SB * tpr;                               // (the launcher checks that this fits)
     float W4[NSETS][CV_KMAX], bias[NSETS];
-    int revs[NSETS];
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const cad_conv1d_args& a = sets.s[s];
-        revs[s] = sb < a.split ? a.rev_lo : a.rev_hi;
         load_w4(a.w, e, a.K, W4[s]);
         bias[s] = a.bias ? a.bias[e] : 0.f;
     }
-    const int64_t tile0 = (int64_t)blockIdx.y * CV_TILES_FWD * CV_WAVES + wave;
-    if (tile0 * CV_WAVE_POS >= L) return;  // wave-uniform
+    const uint32_t v0 = blockIdx.y * (CV_TILES_FWD * CV_WAVES) + wave;
+    if (v0 >= nvt) return;  // wave-uniform
     const bool useful = lane >= 1 && lane <= 62;
-    CvRaw<T> raw = load8_raw<T, VEC>(x, tile0 * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC, L);
+    auto locate = [&](uint32_t v, int64_t& row, int64_t& sb, int64_t& l0) {
+        const uint32_t r = v / tpr;
+        sb = r;
+        row = (int64_t)e * SB + r;
+        l0 = (int64_t)(v - r * tpr) * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
+    };
+    int64_t row, sb, l0;
+    locate(v0, row, sb, l0);
+    CvRaw<T> raw = load8_raw<T, VEC>((const T*)a0.x + row * L, l0, L);
     CvRaw<T> po[NSETS];      // the previous tile's packed results (VEC), stored one tile late
-    int64_t l0_prev = 0;
+    int64_t l0_prev = 0, row_prev = 0;
     for (int it = 0; it < CV_TILES_FWD; ++it) {
-        const int64_t tile = tile0 + (int64_t)it * CV_WAVES;  // the workgroup's waves cover 4 neighbouring tiles at a time
-        if (tile * CV_WAVE_POS >= L) break;                   // wave-uniform
-        const int64_t l0 = tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
+        const uint32_t v = v0 + it * CV_WAVES;  // the workgroup's waves cover 4 neighbouring tiles at a time
+        if (v >= nvt) break;                     // wave-uniform
         float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO];
         cvt8<T, VEC>(raw, l0, L, own);
         if constexpr (VEC) {
@@ -192,10 +199,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets
 #endif
             if (it > 0 && useful) {
 #pragma unroll
-                for (int s = 0; s < NSETS; ++s) store_raw<T>((T*)sets.s[s].out + rowid * L, l0_prev, L, po[s]);
+                for (int s = 0; s < NSETS; ++s) store_raw<T>((T*)sets.s[s].out + row_prev * L, l0_prev, L, po[s]);
             }
         }
-        if (it + 1 < CV_TILES_FWD && (tile + CV_WAVES) * CV_WAVE_POS < L) raw = load8_raw<T, VEC>(x, l0 + (int64_t)CV_WAVES * CV_WAVE_POS, L);
+        const int64_t row_c = row, sb_c = sb, l0_c = l0;
+        if (it + 1 < CV_TILES_FWD && v + CV_WAVES < nvt) {
+            locate(v + CV_WAVES, row, sb, l0);
+            raw = load8_raw<T, VEC>((const T*)a0.x + row * L, l0, L);
+        }
         halo_window(own, xe);
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
@@ -208,19 +219,21 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets
                     o[j] = acc * cad_sigmoid(acc);
                 }
             };
-            if (revs[s]) body(DirTag<1>{}); else body(DirTag<0>{});
+            const int rev = sb_c < sets.s[s].split ? sets.s[s].rev_lo : sets.s[s].rev_hi;  // wave-uniform: the tile's row
+            if (rev) body(DirTag<1>{}); else body(DirTag<0>{});
             if constexpr (VEC) {
                 po[s] = pack8<T>(o);
             } else {
-                if (useful) store8v<T, VEC>((T*)sets.s[s].out + rowid * L, l0, L, o);
+                if (useful) store8v<T, VEC>((T*)sets.s[s].out + row_c * L, l0_c, L, o);
             }
         }
-        l0_prev = l0;
+        l0_prev = l0_c;
+        row_prev = row_c;
     }
     if constexpr (VEC) {
         if (useful) {  // (at least one tile was computed: the wave returned above otherwise)
 #pragma unroll
-            for (int s = 0; s < NSETS; ++s) store_raw<T>((T*)sets.s[s].out + rowid * L, l0_prev, L, po[s]);
+            for (int s = 0; s < NSETS; ++s) store_raw<T>((T*)sets.s[s].out + row_prev * L, l0_prev, L, po[s]);
         }
     }
 }
@@ -231,59 +244,62 @@ template <typename T, int NSETS, bool VEC, bool ACC>
 __global__ __launch_bounds__(CV_THREADS, CV_BWD_WAVES) void conv1d_bwd_kernel(ConvBwdSets sets) {
     __shared__ float red[CV_WAVES][NSETS][CV_KMAX + 1];
     const cad_conv1d_bwd_args& a0 = sets.s[0];
-    const int64_t rowid = blockIdx.x;
-    const int e = (int)(rowid / a0.SB);
-    const int64_t sb = rowid - (int64_t)e * a0.SB;
-    const int64_t L = a0.L;
+    const int e = blockIdx.x;  // one channel per workgroup, virtual tiles over its rows (see the forward)
+    const int64_t L = a0.L, SB = a0.SB;
     const int lane = threadIdx.x & 63;
     const int wave = cad_uniform(threadIdx.x >> 6);
-    const T* x = (const T*)a0.x + rowid * L;
-    T* dx = (T*)a0.dx + rowid * L;
+    const uint32_t tpr = (uint32_t)((L + CV_WAVE_POS - 1) / CV_WAVE_POS);
+    const uint32_t nvt = (uint32_t)SB * tpr;
     float W4[NSETS][CV_KMAX], bias[NSETS], part[NSETS][CV_KMAX + 1];  // part: dw4[0..3], dbias
-    int revs[NSETS];
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const cad_conv1d_bwd_args& a = sets.s[s];
-        revs[s] = sb < a.split ? a.rev_lo : a.rev_hi;
         load_w4(a.w, e, a.K, W4[s]);
 #pragma unroll
         for (int m = 0; m <= CV_KMAX; ++m) part[s][m] = 0.f;
         bias[s] = a.bias ? a.bias[e] : 0.f;
     }
     const float useful = (lane >= 1 && lane <= 62) ? 1.f : 0.f;
-    // all loads of a tile (x, the dx addend, dout of every set) are issued one tile ahead, raw, and converted when the tile is computed
+    auto locate = [&](uint32_t v, int64_t& row, int64_t& sb, int64_t& l0) {
+        const uint32_t r = v / tpr;
+        sb = r;
+        row = (int64_t)e * SB + r;
+        l0 = (int64_t)(v - r * tpr) * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
+    };
+    // all loads of a tile (x, dout of every set) are issued one tile ahead, raw, and converted when the tile is computed
     // (the dx addend is loaded at the start of its own tile and added last: the arithmetic of the tile covers most of its latency)
     CvRaw<T> rx, rg[NSETS];
-    auto fetch = [&](int64_t l0) {
-        rx = load8_raw<T, VEC>(x, l0, L);
+    int64_t row = 0, sb = 0, l0 = 0;  // of the tile in flight
+    auto fetch = [&](uint32_t v) {
+        locate(v, row, sb, l0);
+        rx = load8_raw<T, VEC>((const T*)a0.x + row * L, l0, L);
 #pragma unroll
-        for (int s = 0; s < NSETS; ++s) rg[s] = load8_raw<T, VEC>((const T*)sets.s[s].dout + rowid * L, l0, L);
+        for (int s = 0; s < NSETS; ++s) rg[s] = load8_raw<T, VEC>((const T*)sets.s[s].dout + row * L, l0, L);
     };
-    {
-        const int64_t tile = (int64_t)blockIdx.y * CV_TILES_BWD * CV_WAVES + wave;
-        if (tile * CV_WAVE_POS < L) fetch(tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC);
-    }
+    const uint32_t v0 = blockIdx.y * (CV_TILES_BWD * CV_WAVES) + wave;
+    if (v0 < nvt) fetch(v0);
     // (the dx store is NOT delayed by a tile as the forward's stores are: measured equal, 0.260-0.265 against 0.261-0.266 ms, for four
     // more registers -- the backward's tile arithmetic is long enough to cover it)
     for (int it = 0; it < CV_TILES_BWD; ++it) {
-        const int64_t tile = ((int64_t)blockIdx.y * CV_TILES_BWD + it) * CV_WAVES + wave;
-        if (tile * CV_WAVE_POS >= L) break;  // wave-uniform
-        const int64_t l0 = tile * CV_WAVE_POS + (int64_t)(lane - 1) * CV_VEC;
+        const uint32_t v = v0 + it * CV_WAVES;
+        if (v >= nvt) break;  // wave-uniform
+        const int64_t row_c = row, sb_c = sb, l0_c = l0;
+        T* dx = (T*)a0.dx + row_c * L;
         float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO], o[CV_VEC];
-        cvt8<T, VEC>(rx, l0, L, own);
+        cvt8<T, VEC>(rx, l0_c, L, own);
         CvRaw<T> rdx;  // (ACC is a template parameter: a run-time branch would merge the register behind it and wait for the load there)
-        if constexpr (ACC) rdx = load8_raw<T, VEC>((const T*)dx, l0, L);
+        if constexpr (ACC) rdx = load8_raw<T, VEC>((const T*)dx, l0_c, L);
 #pragma unroll
         for (int j = 0; j < CV_VEC; ++j) o[j] = 0.f;
         CvRaw<T> cg[NSETS];  // this tile's dout, still raw: converted set by set
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) cg[s] = rg[s];
-        if (it + 1 < CV_TILES_BWD && (tile + CV_WAVES) * CV_WAVE_POS < L) fetch(l0 + (int64_t)CV_WAVES * CV_WAVE_POS);
+        if (it + 1 < CV_TILES_BWD && v + CV_WAVES < nvt) fetch(v + CV_WAVES);
         halo_window(own, xe);
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
             float g[CV_VEC], dpre[CV_VEC], dpe[CV_VEC + 2 * CV_HALO];
-            cvt8<T, VEC>(cg[s], l0, L, g);
+            cvt8<T, VEC>(cg[s], l0_c, L, g);
             auto body = [&](auto dir) {
                 constexpr int REV = decltype(dir)::value;
 #pragma unroll
@@ -302,15 +318,16 @@ __global__ __launch_bounds__(CV_THREADS, CV_BWD_WAVES) void conv1d_bwd_kernel(Co
                     part[s][CV_KMAX] += dm;
                 }
             };
-            if (revs[s]) body(DirTag<1>{}); else body(DirTag<0>{});
+            const int rev = sb_c < sets.s[s].split ? sets.s[s].rev_lo : sets.s[s].rev_hi;  // wave-uniform: the tile's row
+            if (rev) body(DirTag<1>{}); else body(DirTag<0>{});
         }
         if constexpr (ACC) {
             float add[CV_VEC];
-            cvt8<T, VEC>(rdx, l0, L, add);
+            cvt8<T, VEC>(rdx, l0_c, L, add);
 #pragma unroll
             for (int j = 0; j < CV_VEC; ++j) o[j] += add[j];
         }
-        if (useful != 0.f) store8v<T, VEC>(dx, l0, L, o);
+        if (useful != 0.f) store8v<T, VEC>(dx, l0_c, L, o);
     }
     // workgroup reduction of the dw / dbias partials, then a handful of atomics per workgroup
 #pragma unroll
@@ -359,8 +376,10 @@ extern "C" int cad_conv1d_fwd_multi(const cad_conv1d_args* sets, int nsets, void
     for (int i = nsets; i < CV_MAXSETS; ++i) ks.s[i] = sets[0];
     const cad_conv1d_args* a = &sets[0];
     CadProfScope prof(2, stream);
-    const int64_t per_block = (int64_t)CV_WAVES * CV_WAVE_POS * CV_TILES_FWD;
-    dim3 grid((unsigned)((int64_t)a->E * a->SB), (unsigned)((a->L + per_block - 1) / per_block)), block(CV_THREADS);
+    const int64_t nvt = a->SB * ((a->L + CV_WAVE_POS - 1) / CV_WAVE_POS);  // virtual tiles of one channel
+    if (nvt >= (1LL << 31)) return CAD_ERR_UNSUPPORTED;
+    const int64_t per_block = (int64_t)CV_WAVES * CV_TILES_FWD;
+    dim3 grid((unsigned)a->E, (unsigned)((nvt + per_block - 1) / per_block)), block(CV_THREADS);
     if (grid.y > 65535u) return CAD_ERR_UNSUPPORTED;
     const size_t vb = (a->dtype == CAD_F32 ? 4 : 2) * CV_VEC;
     uintptr_t ptrs = (uintptr_t)a->x;
@@ -401,8 +420,10 @@ extern "C" int cad_conv1d_bwd_multi(const cad_conv1d_bwd_args* sets, int nsets, 
     for (int i = nsets; i < CV_MAXSETS; ++i) ks.s[i] = sets[0];
     const cad_conv1d_bwd_args* a = &sets[0];
     CadProfScope prof(3, stream);
-    const int64_t per_block = (int64_t)CV_WAVES * CV_WAVE_POS * CV_TILES_BWD;
-    dim3 grid((unsigned)((int64_t)a->E * a->SB), (unsigned)((a->L + per_block - 1) / per_block)), block(CV_THREADS);
+    const int64_t nvt = a->SB * ((a->L + CV_WAVE_POS - 1) / CV_WAVE_POS);
+    if (nvt >= (1LL << 31)) return CAD_ERR_UNSUPPORTED;
+    const int64_t per_block = (int64_t)CV_WAVES * CV_TILES_BWD;
+    dim3 grid((unsigned)a->E, (unsigned)((nvt + per_block - 1) / per_block)), block(CV_THREADS);
     if (grid.y > 65535u) return CAD_ERR_UNSUPPORTED;
     const size_t vb = (a->dtype == CAD_F32 ? 4 : 2) * CV_VEC;
     uintptr_t ptrs = (uintptr_t)a->x | (uintptr_t)a->dx;

@@ -94,7 +94,8 @@ def test_selective_scan_golden(backend, shape, golden_dir):
 
 
 @pytest.mark.parametrize("case", [(5, 2, 75, 4, 1, 0, 1), (3, 1, 8, 4, 1, 1, 1), (4, 3, 2100, 3, 1, 0, 1),
-                                  (2, 1, 1, 4, 0, 0, 0), (6, 2, 4096, 2, 2, 1, 0), (2, 2, 17000, 4, 1, 0, 1)])
+                                  (2, 1, 1, 4, 0, 0, 0), (6, 2, 4096, 2, 2, 1, 0), (2, 2, 17000, 4, 1, 0, 1),
+                                  (3, 70, 1024, 4, 30, 0, 1), (2, 45, 200, 4, 45, 1, 0)])  # many short rows per channel
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_causal_conv1d(backend, case, dtype):
     name, dev = backend
@@ -253,7 +254,7 @@ def test_lm_head_and_loss(backend, n_strands, dtype, V, D, B, L):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(5, 2, 75, 4), (3, 3, 2100, 3), (6, 2, 4096, 4), (2, 2, 34000, 4)])
+@pytest.mark.parametrize("case", [(5, 2, 75, 4), (3, 3, 2100, 3), (6, 2, 4096, 4), (2, 2, 34000, 4), (2, 50, 1024, 4)])
 def test_causal_conv1d_two_sets(backend, case, dtype):
     """cad_conv1d_fwd_multi / cad_conv1d_bwd_multi (two parameter sets on one x, opposite directions, dx summed) are
     identical to two single-set launches."""
