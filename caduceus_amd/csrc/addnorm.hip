@@ -182,7 +182,8 @@ __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float* o) {
     o[2] = cad_bits2f(t.w[1] << 16), o[3] = cad_bits2f(t.w[1] & 0xffff0000u);
 }
 
-// KMAX = 256-channel steps per lane: 1 for D <= 256 (a third of the registers of the general instantiation, twice the waves per SIMD)
+// KMAX = 256-channel steps per lane: 1 for D <= 256 (a third of the registers of the general instantiation, twice the waves per
+// SIMD), 2 for D <= 512 (configs[4])
 template <typename TX, typename TY, int KMAX>
 __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add_norm_args a) {
     const int lane = threadIdx.x & 63;
@@ -385,6 +386,8 @@ extern "C" int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream) {
     do {                                                                                \
         if (vec && a->D <= 256)                                                         \
             CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, 1>), grid, block, 0, stream, *a);  \
+        else if (vec && a->D <= 512)                                                    \
+            CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, 2>), grid, block, 0, stream, *a);  \
         else if (vec)                                                                   \
             CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, ANV_KMAX>), grid, block, 0, stream, *a);  \
         else                                                                            \
@@ -418,6 +421,8 @@ extern "C" int cad_add_norm_bwd(const cad_add_norm_bwd_args* a, void* stream) {
     do {                                                                                \
         if (vec && a->D <= 256)                                                         \
             CAD_LAUNCH((add_norm_bwd_vec_kernel<TX, TY, 1>), grid, block, 0, stream, *a, rows_per_wave);  \
+        else if (vec && a->D <= 512)                                                    \
+            CAD_LAUNCH((add_norm_bwd_vec_kernel<TX, TY, 2>), grid, block, 0, stream, *a, rows_per_wave);  \
         else if (vec)                                                                   \
             CAD_LAUNCH((add_norm_bwd_vec_kernel<TX, TY, ANV_KMAX>), grid, block, 0, stream, *a, rows_per_wave);  \
         else                                                                            \

@@ -144,7 +144,7 @@ def _ref_add_norm(x, res, w, b, eps, is_rms, swap_flip):
     return y, s
 
 
-@pytest.mark.parametrize("S,R,D", [(2, 37, 32), (1, 64, 256), (2, 5, 130), (2, 16, 1024)])
+@pytest.mark.parametrize("S,R,D", [(2, 37, 32), (1, 64, 256), (2, 5, 130), (2, 9, 512), (2, 16, 1024)])
 @pytest.mark.parametrize("is_rms", [True, False])
 @pytest.mark.parametrize("swap_flip", [False, True])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
