@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_fwd_kernel(cad_lm_head_
     }
 }
 
-// Matrix-core variant (D = 32 NJ, NJ in {4, 8}: d_model 128 / 256).  A wave owns 16-token tiles: logits (16 x 16) =
+// Matrix-core variant (D = 32 NJ, NJ in {4, 8, 16}: d_model 128 / 256 / 512).  A wave owns 16-token tiles: logits (16 x 16) =
 // H (16 x D) . W^T with v_mfma_f32_16x16x4_f32 -- fp32 operands, so W stays the fp32 master weight -- one accumulator tile per
 // strand.  The k axis is walked in a permuted order that makes both operands 16-byte vector loads: MFMA number 8 j + e takes, from
 // lane (token or vocabulary row, k-group g), element  k = 8 g + 32 j + e.  W (64 or fewer floats per lane) is loaded once per wave.
@@ -414,7 +414,9 @@ __global__ __launch_bounds__(LM_FOLD_THREADS) void lm_loss_fold_kernel(const flo
 
 }  // namespace
 
-static bool lm_head_mfma(int D) { return D == 128 || D == 256; }  // W resident in registers: 32 / 64 VGPRs
+// W resident in registers: 32 / 64 VGPRs; d_model 512 (configs[4]) with 128, in bf16 only (363 registers, one wave per SIMD: the fp32
+// instantiation would spill)
+static bool lm_head_mfma(int D, int dtype) { return D == 128 || D == 256 || (D == 512 && dtype == CAD_BF16); }
 // (the number of per-workgroup loss slots depends on rows only, so that the caller can size them without knowing D: the matrix-core
 // kernel uses at most as many workgroups as the general one)
 static int64_t lm_head_blocks(int64_t rows) {
@@ -436,7 +438,7 @@ extern "C" int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream) {
     if (a->V > LM_VMAX) return CAD_ERR_UNSUPPORTED;
     CadProfScope prof(7, stream);
     if (a->dtype != CAD_F32 && a->dtype != CAD_BF16) return CAD_ERR_UNSUPPORTED;
-    const bool mfma = lm_head_mfma(a->D) && ((uintptr_t)a->hidden % 32) == 0;
+    const bool mfma = lm_head_mfma(a->D, a->dtype) && ((uintptr_t)a->hidden % 32) == 0;
     const int64_t nb = mfma ? lm_head_blocks_mfma(a->rows) : lm_head_blocks(a->rows);
     dim3 grid((unsigned)nb), block(64 * LM_WAVES);
 #define LM_MFMA(NJ_)                                                                              \
@@ -448,8 +450,10 @@ extern "C" int cad_lm_head_fwd(const cad_lm_head_args* a, void* stream) {
     } while (0)
     if (mfma && a->D == 128)
         LM_MFMA(4);
-    else if (mfma)
+    else if (mfma && a->D == 256)
         LM_MFMA(8);
+    else if (mfma)
+        CAD_LAUNCH((lm_head_fwd_mfma_kernel<bf16_t, 16>), grid, block, 0, stream, *a);
     else if (a->dtype == CAD_F32)
         CAD_LAUNCH((lm_head_fwd_kernel<float>), grid, block, 0, stream, *a);
     else

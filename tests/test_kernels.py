@@ -228,7 +228,7 @@ def test_embed(backend, n_strands, D):
 
 @pytest.mark.parametrize("n_strands", [1, 2])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("V,D,B,L", [(16, 40, 2, 300), (16, 256, 2, 301), (12, 128, 1, 75), (16, 256, 1, 9000)])
+@pytest.mark.parametrize("V,D,B,L", [(16, 40, 2, 300), (16, 256, 2, 301), (12, 128, 1, 75), (16, 256, 1, 9000), (16, 512, 1, 200)])
 def test_lm_head_and_loss(backend, n_strands, dtype, V, D, B, L):
     """D = 40: the general kernel; D = 128 / 256: the matrix-core kernel (fp32 MFMA, 16-token tiles -- ragged last tile, a vocabulary
     smaller than the tile, enough tiles for several per wave)."""
