@@ -537,3 +537,32 @@ def test_scan_lsplit_two_pass_matches_unsplit_and_oracle(backend, monkeypatch, d
     ref = _rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, A, B_, C_, D, z_, b), [u, d, B, C, z], split, 0, 1)
     otol = FP32 if dtype == torch.float32 else BF16
     torch.testing.assert_close(b1.float().cpu(), ref.detach(), **otol)
+
+
+def test_kernel_timer_counts_only_the_enabled_kinds(backend):
+    """cad_prof_enable_kinds: launches of a kind whose bit is not set are not timed (bench.py times the two scan kinds only inside its
+    timed region -- every timed launch costs two event records on the stream); cad_prof_enable(1) times every kind."""
+    from caduceus_amd import _lib as CL
+    name, dev = backend
+    x = torch.randn(4, 2, 64).to(dev)
+    w, b = torch.randn(4, 1, 4).to(dev), torch.randn(4).to(dev)
+    h, nw = torch.randn(1, 1, 8, 32).to(dev), torch.ones(32).to(dev)
+    CL.prof_enable(False)
+    CL.prof_reset()
+    try:
+        CL.prof_enable(True, kinds=("conv_fwd",))
+        ops.causal_conv1d(x, w, b, 2, 0, 0)
+        ops.add_norm(h, None, nw, None, 1e-5, True, False, torch.float32)
+        CL.prof_enable(False)
+        pr = CL.prof_read()
+        assert pr["conv_fwd"][1] == 1 and pr["add_norm_fwd"][1] == 0
+        CL.prof_reset()
+        CL.prof_enable(True)
+        ops.causal_conv1d(x, w, b, 2, 0, 0)
+        ops.add_norm(h, None, nw, None, 1e-5, True, False, torch.float32)
+        CL.prof_enable(False)
+        pr = CL.prof_read()
+        assert pr["conv_fwd"][1] == 1 and pr["add_norm_fwd"][1] == 1
+    finally:
+        CL.prof_enable(False)
+        CL.prof_reset()
