@@ -12,6 +12,16 @@ LIB = os.path.join(HERE, "libcaduceus_emu" + ("_" + "_".join(d.replace("=", "") 
 
 
 def build_emu(force: bool = False) -> str:
+    """Several pytest-xdist workers may ask for the library at once: one builds (file lock), the link goes to a
+    temporary name and is renamed into place, so nobody ever maps a half-written file."""
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", os.path.basename(LIB) + ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_emu_locked(force)
+
+
+def _build_emu_locked(force: bool) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "emu_runtime.*")) + \
         [os.path.join(ROOT, "include", "caduceus_hip.h")]
@@ -36,7 +46,9 @@ def build_emu(force: bool = False) -> str:
         if p.returncode != 0:
             raise RuntimeError(f"g++ (emu) failed for {s}:\n{out.decode()}")
         objs.append(obj)
-    subprocess.check_call(["g++", "-shared", "-fPIC", *objs, "-o", LIB])
+    tmp = LIB + f".tmp{os.getpid()}"
+    subprocess.check_call(["g++", "-shared", "-fPIC", *objs, "-o", tmp])
+    os.replace(tmp, LIB)
     return LIB
 
 
