@@ -29,7 +29,7 @@ def _build_emu_locked(force: bool) -> str:
         return LIB
     objdir = os.path.join(HERE, "build", os.path.basename(LIB))
     os.makedirs(objdir, exist_ok=True)
-    flags = ["-O2", "-std=c++17", "-fPIC", "-DCAD_EMU", "-I", HERE, "-Wno-attributes", "-Wno-unknown-pragmas"]
+    flags = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-DCAD_EMU", "-I", HERE, "-Wno-attributes", "-Wno-unknown-pragmas"]
     flags += [f"-D{d}" for d in _DEFS]
     procs = []
     for s in srcs:
@@ -47,7 +47,7 @@ def _build_emu_locked(force: bool) -> str:
             raise RuntimeError(f"g++ (emu) failed for {s}:\n{out.decode()}")
         objs.append(obj)
     tmp = LIB + f".tmp{os.getpid()}"
-    subprocess.check_call(["g++", "-shared", "-fPIC", *objs, "-o", tmp])
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-fopenmp", *objs, "-o", tmp])
     os.replace(tmp, LIB)
     return LIB
 

@@ -1,7 +1,12 @@
 // Fiber scheduler of the host emulator (see emu_runtime.h).  TEST INFRASTRUCTURE ONLY.
 #include "emu_runtime.h"
 
+#include <sys/mman.h>
+
+#include <algorithm>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 // Minimal x86-64 SysV context switch (callee-saved registers + stack pointer).  glibc's swapcontext() issues a
@@ -34,7 +39,11 @@ emu_switch:
 )");
 
 namespace emu {
-dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+// Workgroups are independent, so a launch spreads them over OS threads (OpenMP, dynamic schedule); every fiber of one workgroup
+// runs on the thread that picked the workgroup up, all scheduler state is thread-local.  Global-memory atomics of the kernels are
+// real atomics (emu_runtime.h), `__shared__` arrays are thread-local statics.  CAD_EMU_THREADS=1 restores the serial schedule.
+thread_local dim3 g_threadIdx, g_blockIdx;
+dim3 g_blockDim, g_gridDim;
 
 namespace {
 constexpr size_t kStack = 256 * 1024;
@@ -52,130 +61,166 @@ struct WaveState {
     int arrived = 0, alive = 0;
     uint64_t buf[128];
 };
-std::vector<Fiber> fibers;
-std::vector<WaveState> waves;
-std::vector<char> stacks;
-std::vector<char> dynsmem;
-void* sched_sp = nullptr;
-Fiber* cur = nullptr;
-unsigned block_gen = 0;
-int block_arrived = 0, block_alive = 0;
+// per OS thread: the workgroup it is running
+struct Worker {
+    std::vector<Fiber> fibers;
+    std::vector<WaveState> waves;
+    char* stacks = nullptr;  // mmap'ed, touched lazily (a fiber uses a few KB of its 256 KB)
+    size_t stacks_bytes = 0;
+    std::vector<char> dynsmem;
+    void* sched_sp = nullptr;
+    Fiber* cur = nullptr;
+    unsigned block_gen = 0;
+    int block_arrived = 0, block_alive = 0;
+    ~Worker() {
+        if (stacks) munmap(stacks, stacks_bytes);
+    }
+};
+thread_local Worker tw;
 const std::function<void()>* body_fn = nullptr;
 std::mutex launch_mu;
 
-void yield() { emu_switch(&cur->sp, sched_sp); }
+void yield() { emu_switch(&tw.cur->sp, tw.sched_sp); }
 
 void trampoline() {
     (*body_fn)();
-    cur->done = true;
+    Worker& w_ = tw;
+    w_.cur->done = true;
     // a finished thread no longer takes part in barriers
-    block_alive--;
-    WaveState& w = waves[cur->wave];
+    w_.block_alive--;
+    WaveState& w = w_.waves[w_.cur->wave];
     w.alive--;
-    if (block_alive > 0 && block_arrived == block_alive) {
-        block_arrived = 0;
-        block_gen++;
+    if (w_.block_alive > 0 && w_.block_arrived == w_.block_alive) {
+        w_.block_arrived = 0;
+        w_.block_gen++;
     }
     if (w.alive > 0 && w.arrived == w.alive) {
         w.arrived = 0;
         w.gen++;
     }
-    emu_switch(&cur->sp, sched_sp);
+    emu_switch(&w_.cur->sp, w_.sched_sp);
     std::abort();  // a finished fiber is never resumed
+}
+
+int max_threads() {
+    static const int n = [] {
+        const char* e = std::getenv("CAD_EMU_THREADS");
+        int v = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(v, 32));
+    }();
+    return n;
+}
+
+void run_block(unsigned bx, unsigned by, unsigned bz, dim3 block, size_t dyn_bytes) {
+    Worker& W = tw;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    const int nwaves = (nthreads + 63) / 64;
+    if ((int)W.fibers.size() < nthreads) W.fibers.resize(nthreads);
+    if (W.stacks_bytes < (size_t)nthreads * kStack) {
+        if (W.stacks) munmap(W.stacks, W.stacks_bytes);
+        W.stacks_bytes = (size_t)nthreads * kStack;
+        void* m = mmap(nullptr, W.stacks_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (m == MAP_FAILED) {
+            std::fprintf(stderr, "emu: cannot map %zu bytes of fiber stacks\n", W.stacks_bytes);
+            std::abort();
+        }
+        W.stacks = (char*)m;
+    }
+    if (W.dynsmem.size() < dyn_bytes + 64) W.dynsmem.resize(dyn_bytes + 64);
+    if ((int)W.waves.size() < nwaves) W.waves.resize(nwaves);
+    g_blockIdx = dim3(bx, by, bz);
+    W.block_gen = 0;
+    W.block_arrived = 0;
+    W.block_alive = nthreads;
+    for (int w = 0; w < nwaves; ++w) {
+        W.waves[w].gen = 0;
+        W.waves[w].arrived = 0;
+        W.waves[w].alive = std::min(64, nthreads - 64 * w);
+    }
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber& f = W.fibers[t];
+        f.done = false;
+        f.wait = NONE;
+        f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        f.wave = t / 64;
+        f.lane = t % 64;
+        f.parity = 0;
+        // initial frame: six callee-saved slots + return address = trampoline; the stack pointer at
+        // trampoline entry must be 8 (mod 16) as after a `call`
+        uintptr_t top = ((uintptr_t)(W.stacks + (size_t)(t + 1) * kStack)) & ~(uintptr_t)15;
+        void** frame = (void**)(top - 64);
+        for (int q = 0; q < 6; ++q) frame[q] = nullptr;
+        frame[6] = (void*)trampoline;
+        f.sp = (void*)frame;
+    }
+    int remaining = nthreads;
+    while (remaining > 0) {
+        bool progressed = false;
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = W.fibers[t];
+            if (f.done) continue;
+            if (f.wait == BLOCK && f.wait_gen == W.block_gen) continue;
+            if (f.wait == WAVE && f.wait_gen == W.waves[f.wave].gen) continue;
+            f.wait = NONE;
+            W.cur = &f;
+            g_threadIdx = f.tid;
+            emu_switch(&W.sched_sp, f.sp);
+            progressed = true;
+            if (f.done) remaining--;
+        }
+        if (!progressed) {
+            std::fprintf(stderr, "emu: deadlock in block (%u,%u,%u): divergent barrier/shuffle\n", bx, by, bz);
+            std::abort();
+        }
+    }
 }
 }  // namespace
 
 void syncthreads() {
-    block_arrived++;
-    if (block_arrived == block_alive) {
-        block_arrived = 0;
-        block_gen++;
+    Worker& W = tw;
+    W.block_arrived++;
+    if (W.block_arrived == W.block_alive) {
+        W.block_arrived = 0;
+        W.block_gen++;
         return;
     }
-    cur->wait = BLOCK;
-    cur->wait_gen = block_gen;
+    W.cur->wait = BLOCK;
+    W.cur->wait_gen = W.block_gen;
     yield();
 }
 
 void wave_sync() {
-    WaveState& w = waves[cur->wave];
+    Worker& W = tw;
+    WaveState& w = W.waves[W.cur->wave];
     w.arrived++;
     if (w.arrived == w.alive) {
         w.arrived = 0;
         w.gen++;
         return;
     }
-    cur->wait = WAVE;
-    cur->wait_gen = w.gen;
+    W.cur->wait = WAVE;
+    W.cur->wait_gen = w.gen;
     yield();
 }
 
-uint64_t* wave_buf() { return waves[cur->wave].buf; }
-int lane_id() { return cur->lane; }
-int& lane_parity() { return cur->parity; }
-int wave_lanes() { return waves[cur->wave].alive; }
-char* dyn_smem() { return dynsmem.data(); }
+uint64_t* wave_buf() { return tw.waves[tw.cur->wave].buf; }
+int lane_id() { return tw.cur->lane; }
+int& lane_parity() { return tw.cur->parity; }
+int wave_lanes() { return tw.waves[tw.cur->wave].alive; }
+char* dyn_smem() { return tw.dynsmem.data(); }
 
 void launch(dim3 grid, dim3 block, size_t dyn_bytes, const std::function<void()>& body) {
     std::lock_guard<std::mutex> lk(launch_mu);
-    const int nthreads = (int)(block.x * block.y * block.z);
-    const int nwaves = (nthreads + 63) / 64;
-    if ((int)fibers.size() < nthreads) fibers.resize(nthreads);
-    if (stacks.size() < (size_t)nthreads * kStack) stacks.resize((size_t)nthreads * kStack);
-    if (dynsmem.size() < dyn_bytes + 64) dynsmem.resize(dyn_bytes + 64);
-    waves.assign(nwaves, WaveState());
     g_blockDim = block;
     g_gridDim = grid;
     body_fn = &body;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                g_blockIdx = dim3(bx, by, bz);
-                block_gen = 0;
-                block_arrived = 0;
-                block_alive = nthreads;
-                for (int w = 0; w < nwaves; ++w) {
-                    waves[w].gen = 0;
-                    waves[w].arrived = 0;
-                    waves[w].alive = std::min(64, nthreads - 64 * w);
-                }
-                for (int t = 0; t < nthreads; ++t) {
-                    Fiber& f = fibers[t];
-                    f.done = false;
-                    f.wait = NONE;
-                    f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                    f.wave = t / 64;
-                    f.lane = t % 64;
-                    f.parity = 0;
-                    // initial frame: six callee-saved slots + return address = trampoline; the stack pointer at
-                    // trampoline entry must be 8 (mod 16) as after a `call`
-                    uintptr_t top = ((uintptr_t)(stacks.data() + (size_t)(t + 1) * kStack)) & ~(uintptr_t)15;
-                    void** frame = (void**)(top - 64);
-                    for (int q = 0; q < 6; ++q) frame[q] = nullptr;
-                    frame[6] = (void*)trampoline;
-                    f.sp = (void*)frame;
-                }
-                int remaining = nthreads;
-                while (remaining > 0) {
-                    bool progressed = false;
-                    for (int t = 0; t < nthreads; ++t) {
-                        Fiber& f = fibers[t];
-                        if (f.done) continue;
-                        if (f.wait == BLOCK && f.wait_gen == block_gen) continue;
-                        if (f.wait == WAVE && f.wait_gen == waves[f.wave].gen) continue;
-                        f.wait = NONE;
-                        cur = &f;
-                        g_threadIdx = f.tid;
-                        emu_switch(&sched_sp, f.sp);
-                        progressed = true;
-                        if (f.done) remaining--;
-                    }
-                    if (!progressed) {
-                        std::fprintf(stderr, "emu: deadlock in block (%u,%u,%u): divergent barrier/shuffle\n", bx, by, bz);
-                        std::abort();
-                    }
-                }
-            }
+    const long total = (long)grid.x * grid.y * grid.z;
+    const int nthr = (int)std::min<long>(max_threads(), total);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthr) if (nthr > 1)
+    for (long b = 0; b < total; ++b) {
+        const unsigned bx = (unsigned)(b % grid.x), by = (unsigned)((b / grid.x) % grid.y), bz = (unsigned)(b / ((long)grid.x * grid.y));
+        run_block(bx, by, bz, block, dyn_bytes);
+    }
     body_fn = nullptr;
 }
 }  // namespace emu

@@ -3,7 +3,7 @@
 // The build container has no GPU.  To exercise the *actual kernel sources* (index maps, wave scans, LDS
 // staging, barriers) against the oracle before spending GPU minutes, tests/emu/build_emu.py compiles the very
 // same .hip files with g++ and -DCAD_EMU; this header then supplies the tiny subset of the HIP device/runtime
-// API the kernels use.  Each GPU thread of a workgroup runs as a ucontext fiber on one OS thread, so
+// API the kernels use.  Each GPU thread of a workgroup runs as a fiber on one OS thread (workgroups are spread over the host's cores), so
 // __syncthreads(), wave64 shuffles and LDS behave with real workgroup semantics (round-robin interleaving).
 //
 // The resulting libcaduceus_emu.so is loaded ONLY by the test-suite through the explicit hook
@@ -22,7 +22,8 @@ struct dim3 {
 };
 
 namespace emu {
-extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+extern thread_local dim3 g_threadIdx, g_blockIdx;  // workgroups of a launch run on several OS threads
+extern dim3 g_blockDim, g_gridDim;
 void launch(dim3 grid, dim3 block, size_t dyn_smem, const std::function<void()>& body);
 void syncthreads();
 void wave_sync();
@@ -42,7 +43,7 @@ char* dyn_smem();
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local  // one workgroup per OS thread at a time
 #define __launch_bounds__(...)
 #ifndef __restrict__
 #define __restrict__
@@ -94,16 +95,20 @@ inline T __shfl_xor(T v, int mask, int width = 64) {
     return emu_exchange(v, src);
 }
 
+// (workgroups run concurrently on several OS threads: global-memory atomics are real ones)
 inline float atomicAdd(float* p, float v) {
-    float o = *p;
-    *p = o + v;
-    return o;
+    uint32_t* q = (uint32_t*)p;
+    uint32_t old = __atomic_load_n(q, __ATOMIC_RELAXED);
+    for (;;) {
+        float o;
+        std::memcpy(&o, &old, 4);
+        const float n = o + v;
+        uint32_t nb;
+        std::memcpy(&nb, &n, 4);
+        if (__atomic_compare_exchange_n(q, &old, nb, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return o;
+    }
 }
-inline int atomicAdd(int* p, int v) {
-    int o = *p;
-    *p = o + v;
-    return o;
-}
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // ---- host runtime subset --------------------------------------------------------------------------
 typedef void* hipStream_t;
