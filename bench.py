@@ -350,7 +350,7 @@ def main():
                                    + (f" x {accum} accumulation micro-steps (global batch {args.global_batch})" if accum > 1 else ""),
                        "global_batch": args.batch * world * accum, "accumulate_grad_batches": accum,
                        "seq_len": args.seqlen, "parallelism": f"dp{world}",
-                       "params": n_params, "final_loss": float(loss)},
+                       "params": n_params, "final_loss": float(loss.detach())},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -42,7 +42,7 @@ def test_fp8_in_proj_in_the_model(backend):
     finally:
         mixer.set_fp8_in_proj(False)
     assert torch.equal(a.logits, b.logits.flip(1)[..., comp])
-    rel = float((a.logits - base.logits).norm() / base.logits.norm())
+    rel = float(((a.logits - base.logits).norm() / base.logits.norm()).detach())
     assert 0 < rel < 0.1, rel  # > 0: the fp8 kernel really ran
     for k in ga:
         assert torch.isfinite(ga[k]).all(), k
