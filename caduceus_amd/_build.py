@@ -33,6 +33,21 @@ def source_hash(defines=()) -> str:
     return h.hexdigest()[:12]
 
 
+SCAN_SOURCES = ("scan_fwd.hip", "scan_bwd.hip", "scan_common.h", "cad_common.h")
+
+
+def scan_source_hash() -> str:
+    """Identifies the sources the two scan kernels are compiled from (their translation units include nothing else of csrc/ besides the
+    C-ABI header).  A counter profile of the scans stays quotable while THESE files are unchanged, whatever happens to the kernels
+    around them (bench.py compares it with the `scan_src` recorded in profiles/r03_scan_pmc.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, n) for n in SCAN_SOURCES] + [os.path.join(HERE, "..", "include", "caduceus_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = LIB, extra_flags=()) -> str:
     """Cross-compiles every kernel for gfx950 (works without a GPU).  Objects are built in parallel.
     `defines` / `out` build tuning variants (e.g. ("SC_S=8",)) next to the default library for A/B measurements."""

@@ -4,6 +4,7 @@
 // One wave64 per token row; lane handles channels c = lane + 64*k.  HBM-bound elementwise kernel: every input
 // byte is read once and every output byte written once; statistics stay in registers (wave xor-reduction).
 #include "cad_common.h"
+#include "cad_stream.h"
 
 namespace {
 
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add
                     o[q] = (v[k][qi] - mean) * rstd * w[q] + b[q];
                     ro[q] = v[k][qi];
                 }
-                cad_cvt_store<TY, 4>(y + orow * D + oc, o);
-                if (a.residual_out) cad_cvt_store<float, 4>(a.residual_out + orow * D + oc, ro);
+                cad_cvt_store_stream<CAD_STREAM_NORM, TY, 4>(y + orow * D + oc, o);
+                if (a.residual_out) cad_cvt_store_stream<CAD_STREAM_NORM, float, 4>(a.residual_out + orow * D + oc, ro);
             }
         }
     }
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_bwd_vec_kernel(cad_add
                     const int qo = a.swap_flip ? (3 - q) : q;  // output element that input element q produced
                     d[q] = rstd * (g[k][qo] - sg - xh[k][qo] * sgx) + dro[qo];
                 }
-                cad_cvt_store<TX, 4>(dx + row * D + c, d);
-                if (a.dres_in) cad_cvt_store<float, 4>(a.dres_in + row * D + c, d);
+                cad_cvt_store_stream<CAD_STREAM_NORM, TX, 4>(dx + row * D + c, d);
+                if (a.dres_in) cad_cvt_store_stream<CAD_STREAM_NORM, float, 4>(a.dres_in + row * D + c, d);
             }
         }
     }

@@ -10,6 +10,7 @@
 // Up to two parameter sets that read the SAME x (mamba_fwd / mamba_rev of a BiMamba layer, which see the same in_proj
 // output in opposite directions) run in one launch: x is read once, and in the backward dx = dx_0 + dx_1 is written once.
 #include "cad_common.h"
+#include "cad_stream.h"
 
 namespace {
 
@@ -100,7 +101,13 @@ __device__ __forceinline__ CvRaw<T> pack8(const float* v) {
 }
 template <typename T>
 __device__ __forceinline__ void store_raw(T* row, int64_t l0, int64_t L, const CvRaw<T>& r) {
-    if (l0 >= 0 && l0 < L) *(CvRaw<T>*)(row + l0) = r;
+    if (l0 >= 0 && l0 < L) {  // written once, read by a later kernel: streaming stores, 16 bytes at a time
+        typedef uint32_t cv4 __attribute__((vector_size(16)));
+        struct P { cv4 q[sizeof(CvRaw<T>) / 16]; };
+        const P p = __builtin_bit_cast(P, r);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(CvRaw<T>) / 16); ++i) cad_store_stream<CAD_STREAM_CONV>((cv4*)(row + l0) + i, p.q[i]);
+    }
 }
 // VEC: one vector store or nothing
 template <typename T, bool VEC>
@@ -110,7 +117,11 @@ __device__ __forceinline__ void store8v(T* row, int64_t l0, int64_t L, const flo
             CvVec<T> tmp;
 #pragma unroll
             for (int j = 0; j < CV_VEC; ++j) tmp.v[j] = from_f32<T>(v[j]);
-            *(CvVec<T>*)(row + l0) = tmp;
+            typedef uint32_t cv4 __attribute__((vector_size(16)));
+            struct P { cv4 q[sizeof(CvVec<T>) / 16]; };
+            const P p = __builtin_bit_cast(P, tmp);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(CvVec<T>) / 16); ++i) cad_store_stream<CAD_STREAM_CONV>((cv4*)(row + l0) + i, p.q[i]);
         }
     } else {
 #pragma unroll

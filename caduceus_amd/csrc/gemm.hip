@@ -16,6 +16,7 @@
 // The per-token arithmetic is independent of the token's position (fixed k order inside the MFMA), so both strands and
 // both directions of the t-frame get bit-identical projections: RC-equivariance stays exact.
 #include "cad_common.h"
+#include "cad_stream.h"
 
 namespace {
 
@@ -165,7 +166,8 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
         if (fast) {
 #pragma unroll
             for (int r0 = 0; r0 < C::MW; r0 += RPI)
-                *(u32x4*)(out + (int64_t)(m_wave + r0 + lane / LPR) * a.ldo + t0 + (lane % LPR) * 8) = sv[r0 / RPI];
+                cad_store_stream<CAD_STREAM_PROJ>((u32x4*)(out + (int64_t)(m_wave + r0 + lane / LPR) * a.ldo + t0 + (lane % LPR) * 8),
+                                                  sv[r0 / RPI]);
         } else {
 #pragma unroll
             for (int r0 = 0; r0 < C::MW; r0 += RPI) {
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wx_kernel(cad_proj_args
                     v[e] = cad_pack_bf16x2(lo, hi);
                 }
             }
-            if (m < M && t + 8 <= T) *(u32x4*)(out + (int64_t)m * a.ldo + t) = v;
+            if (m < M && t + 8 <= T) cad_store_stream<CAD_STREAM_PROJ>((u32x4*)(out + (int64_t)m * a.ldo + t), v);
         }
         __syncthreads();
     }

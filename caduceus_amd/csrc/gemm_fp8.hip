@@ -8,6 +8,7 @@
 //     in the epilogue, so a token's result depends on nothing but that token (position independence: the t-frame strands /
 //     directions stay bit-identical, RC-equivariance exact).
 #include "cad_common.h"
+#include "cad_stream.h"
 
 namespace {
 
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(64 * GF_WAVES, 2) void proj_wxT_fp8_kernel(cad_proj
         if (fast) {
 #pragma unroll
             for (int r0 = 0; r0 < C::MW; r0 += RPI)
-                *(u32x4*)(out + (int64_t)(m_wave + r0 + lane / LPR) * a.ldo + t0 + (lane % LPR) * 8) = sv[r0 / RPI];
+                cad_store_stream<CAD_STREAM_PROJ>((u32x4*)(out + (int64_t)(m_wave + r0 + lane / LPR) * a.ldo + t0 + (lane % LPR) * 8),
+                                                  sv[r0 / RPI]);
         } else {
 #pragma unroll
             for (int r0 = 0; r0 < C::MW; r0 += RPI) {

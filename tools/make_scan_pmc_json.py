@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from caduceus_amd import _lib  # noqa: E402
+from caduceus_amd import _build, _lib  # noqa: E402
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 out_path = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/scan_pmc.json"
@@ -31,7 +31,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.
 res = {"source": "rocprofv3 --pmc passes of tools/prof_scan.sh over tools/layer_bench.py (one production mixer layer) (FETCH_SIZE, WRITE_SIZE and two SQ "
                  "groups, each in its own pass, no tracing combined); per-dispatch averages of the two-set production launches; "
                  "FETCH_SIZE x 2 (gfx950 correction), both size counters reported in KiB",
-       "lib_version": _lib.version(),
+       "lib_version": _lib.version(), "scan_src": _build.scan_source_hash(),
        "shape": {"E": E, "rows": ROWS, "L": L, "N": N, "dtype": "bf16", "sets": 2}, "sq": {}}
 for kind, ctrs in acc.items():
     avg = {c: sum(v) / len(v) for c, v in ctrs.items()}
