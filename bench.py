@@ -114,6 +114,20 @@ def cpu_baseline(scan_L=131072):
 INSTR_PRICE_NS = {"scan_fwd": 0.477, "scan_bwd": 0.977}
 
 
+def pmc_quotable(pmc: dict, lib_version: str):
+    """A committed counter profile of the scans may be quoted next to a timing of THIS library when it was taken on this very build,
+    or on a build whose SCAN sources (scan_*.hip, scan_common.h, cad_common.h, the C-ABI header: `_build.scan_source_hash`) are the
+    ones the loaded library was built from (i.e. the library is the build of the tree the hash is computed on).  Returns the
+    provenance text, or None."""
+    from caduceus_amd import _build
+    if pmc.get("lib_version") == lib_version:
+        return "this build (" + lib_version + ")"
+    if pmc.get("scan_src") and pmc.get("scan_src") == _build.scan_source_hash() and lib_version.endswith(_build.source_hash()):
+        return ("build " + str(pmc.get("lib_version")) + " with the same scan sources (scan_src " + str(pmc.get("scan_src")) +
+                ") as this library, " + lib_version)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,18 +272,11 @@ def main():
             sh = pmc["shape"]
             if dom and (sh["E"], sh["L"], sh["N"], sh["dtype"]) == (E, args.seqlen, N, args.dtype) and \
                     sh["rows"] == (2 if args.model == "ps" else 1) * args.batch:
-                from caduceus_amd import _build
-                # quotable when the profile was taken on this very build, or on a build whose SCAN sources (scan_*.hip, scan_common.h,
-                # cad_common.h, the C-ABI header) are the ones this library was built from
-                same_scan = (pmc.get("scan_src") == _build.scan_source_hash()
-                             and _lib.version().endswith(_build.source_hash()))  # ... and the library is the tree's build
-                if pmc.get("lib_version") == _lib.version() or same_scan:
+                why = pmc_quotable(pmc, _lib.version())
+                if why:
                     traffic = pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"]
                     traffic_note = ("HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
-                                    "profiles/r03_scan_pmc.json taken on " +
-                                    ("this build (" + _lib.version() + ")" if pmc.get("lib_version") == _lib.version() else
-                                     "build " + str(pmc.get("lib_version")) + " with the same scan sources (scan_src " +
-                                     str(pmc.get("scan_src")) + ") as this library, " + _lib.version()))
+                                    "profiles/r03_scan_pmc.json taken on " + why)
                 else:
                     traffic_note = (f"profiles/r03_scan_pmc.json was taken on another build ({pmc.get('lib_version')}); this "
                                     f"library is {_lib.version()}: not quoted")

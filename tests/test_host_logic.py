@@ -143,3 +143,25 @@ def test_chunked_weight_gradient_gemms_match_plain_mm():
     a, b_cm, b_tm = torch.randn(24, T, generator=g), torch.randn(10, T, generator=g), torch.randn(T, 12, generator=g)
     torch.testing.assert_close(mixer._wgrad_cm_cm(a, b_cm), a @ b_cm.t(), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(mixer._wgrad_cm_tm(a, b_tm), a @ b_tm, rtol=1e-4, atol=1e-3)
+
+
+def test_bench_quotes_a_counter_profile_only_for_the_profiled_scan_sources():
+    """bench.pmc_quotable: roofline.traffic comes from profiles/r03_scan_pmc.json only when that profile was taken on the loaded build, or
+    on a build with the same scan sources while the loaded library is the build of this tree."""
+    import importlib.util
+    import os
+    from caduceus_amd import _build
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cur = "caduceus_amd 0.1.0 (hip gfx950) src " + _build.source_hash()
+    pmc = {"lib_version": "caduceus_amd 0.1.0 (hip gfx950) src 000000000000", "scan_src": _build.scan_source_hash()}
+    assert bench.pmc_quotable(dict(pmc, lib_version=cur), cur) == "this build (" + cur + ")"
+    assert "same scan sources" in bench.pmc_quotable(pmc, cur)
+    assert bench.pmc_quotable(dict(pmc, scan_src="ffffffffffff"), cur) is None                    # other scan sources
+    assert bench.pmc_quotable(pmc, "caduceus_amd 0.1.0 (hip gfx950) src 111111111111") is None  # a stale library
+    assert bench.pmc_quotable({"lib_version": pmc["lib_version"]}, cur) is None                   # an unstamped profile
+    # the committed profile is quotable for the committed sources
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r03_scan_pmc.json")))
+    assert bench.pmc_quotable(committed, cur), "profiles/r03_scan_pmc.json does not belong to the scan sources in the tree"
