@@ -99,3 +99,38 @@ def test_async_prefetch_registers_untouched(tmp_path, src):
                 n_loads += 1
                 _walk_to_wait(body, labels, i + 1, _regs(t.split()[1].rstrip(",")), f"{kernel} line {i + 1}")
     assert n_loads >= 8 and n_waits >= 4, (n_loads, n_waits)  # every VEC instantiation contains the pattern
+
+
+def _kernel_bodies(asm):
+    """{mangled kernel name: text of its body} of a gfx950 assembly file."""
+    lines = asm.split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    out = {}
+    for a, b in zip(starts, starts[1:] + [len(lines)]):
+        body = lines[a:b]  # (a kernel may hold several s_endpgm: its end is the .Lfunc_end label)
+        end = next((k for k, l in enumerate(body) if l.startswith(".Lfunc_end")), len(body))
+        out[lines[a].rstrip(":")] = "\n".join(body[:end])
+    return out
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,kernels", [
+    ("gemm.hip", ["proj_wxT_kernel", "proj_wx_kernel"]),
+    ("conv1d.hip", ["conv1d_fwd_kernelI6bf16_tLi2ELb1", "conv1d_bwd_kernelI6bf16_tLi2ELb1"]),  # bf16, both sets, vector path
+    ("addnorm.hip", ["add_norm_fwd_vec_kernelI6bf16_t", "add_norm_bwd_vec_kernelI6bf16_t"]),
+])
+def test_streaming_outputs_leave_with_nontemporal_stores(tmp_path, src, kernels):
+    """csrc/cad_stream.h: the large write-once outputs of the HBM-bound kernels are stored with the `nt` cache policy (131.4 -> 129.8 ms
+    per training step, profiles/r03_ab_nt_stores.txt).  Held on the ISA: every listed (production: bf16, vector path) instantiation must carry
+    nontemporal global stores (a plain store slipping back in would cost the gain silently)."""
+    out = tmp_path / (src + ".s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-S",
+                           "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "caduceus_amd", "csrc", src)],
+                          stderr=subprocess.DEVNULL)
+    bodies = _kernel_bodies(open(out).read())
+    for kern in kernels:
+        inst = [n for n in bodies if kern in n]
+        assert inst, f"{src}: no instantiation of {kern}"
+        for n in inst:
+            nt = len(re.findall(r"global_store_dword\w*\s.*\bnt\b", bodies[n]))
+            assert nt > 0, f"{n}: no nontemporal store"
