@@ -1,0 +1,60 @@
+"""Source-level A/B variants WITHOUT touching the product sources (so the library hash and the committed counter profiles stay valid while
+an idea is being measured): copies caduceus_amd/csrc + include/ to a scratch tree, applies the named edits, cross-compiles
+caduceus_amd/libcaduceus_hip_<name>.so (git-ignored; it travels to the GPU box with gpurun) and leaves the product library alone.
+
+    python tools/exp_variants.py base nt_proj_x_loads ...      # build
+    gpurun -- 'bash tools/ab_bench_libs.sh 2 base nt_proj_x_loads'   # same-box A/B of the whole training step
+
+An edit is (file, old text, new text); `old` must occur exactly once.  Adopt a winner by making the same edit in csrc/ (then the usual
+evidence: GPU suite, bench, and -- if a scan source changed -- tools/prof_scan.sh + tools/make_scan_pmc_json.py)."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRATCH = os.environ.get("CAD_EXP_DIR", "/tmp/cad_exp")
+
+_DMA_NT = ('global_load_lds_dwordx4 %1, off\\n\\ts_mov_b32 m0, %0"', 'global_load_lds_dwordx4 %1, off nt\\n\\ts_mov_b32 m0, %0"')
+VARIANTS = {
+    "base": [],
+    # read-once operands of the projection kernels by LDS-DMA with the nt policy (queued in DESIGN.md section 9 item 10); note that
+    # cad_glds16 is shared with the scans' prefetch (measured there: noise)
+    "nt_dma_loads": [("cad_common.h",) + _DMA_NT],
+    # ordinary stores everywhere (the state before csrc/cad_stream.h)
+    "plain_stores": [("cad_stream.h", "#define CAD_NT_MASK 7", "#define CAD_NT_MASK 0")],
+}
+
+
+def build(name):
+    tree = os.path.join(SCRATCH, name)
+    shutil.rmtree(tree, ignore_errors=True)
+    csrc = os.path.join(tree, "caduceus_amd", "csrc")  # same relative position of include/ as in the repo
+    shutil.copytree(os.path.join(ROOT, "caduceus_amd", "csrc"), csrc)
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tree, "include"))
+    for fname, old, new in VARIANTS[name]:
+        p = os.path.join(csrc, fname)
+        s = open(p).read()
+        assert s.count(old) == 1, f"{name}: `{old[:60]}` occurs {s.count(old)} times in {fname}"
+        open(p, "w").write(s.replace(old, new))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
+             f'-DCAD_SRC_HASH="exp-{name}"']
+    procs = []
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))):
+        procs.append((f + ".o", subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, "-c", f, "-o", f + ".o"])))
+    objs = []
+    for o, p in procs:
+        if p.wait() != 0:
+            raise SystemExit(f"{name}: hipcc failed for {o}")
+        objs.append(o)
+    out = os.path.join(ROOT, "caduceus_amd", f"libcaduceus_hip_{name}.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    print("built", out)
+
+
+if __name__ == "__main__":
+    for n in sys.argv[1:] or ["base"]:
+        if n not in VARIANTS:
+            raise SystemExit(f"unknown variant {n}; known: {', '.join(VARIANTS)}")
+        build(n)
