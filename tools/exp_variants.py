@@ -5,7 +5,7 @@ caduceus_amd/libcaduceus_hip_<name>.so (git-ignored; it travels to the GPU box w
     python tools/exp_variants.py base nt_proj_x_loads ...      # build
     gpurun -- 'bash tools/ab_bench_libs.sh 2 base nt_proj_x_loads'   # same-box A/B of the whole training step
 
-An edit is (file, old text, new text); `old` must occur exactly once.  Adopt a winner by making the same edit in csrc/ (then the usual
+An edit is (file, old text, new text); `old` must occur exactly once (prefix __ALL__: every occurrence).  Adopt a winner by making the same edit in csrc/ (then the usual
 evidence: GPU suite, bench, and -- if a scan source changed -- tools/prof_scan.sh + tools/make_scan_pmc_json.py)."""
 import glob
 import os
@@ -22,6 +22,18 @@ VARIANTS = {
     # read-once operands of the projection kernels by LDS-DMA with the nt policy (queued in DESIGN.md section 9 item 10); note that
     # cad_glds16 is shared with the scans' prefetch (measured there: noise)
     "nt_dma_loads": [("cad_common.h",) + _DMA_NT],
+    # ... the projection kernels only (the candidate for adoption: measured -0.4 ms per step for the family with nt_dma_loads, while nt on
+    # the scans' prefetch alone was noise): a streaming twin of cad_glds16 in cad_stream.h, used by every DMA of gemm.hip / gemm_fp8.hip
+    "nt_proj_x_loads": [
+        ("cad_stream.h", "template <int FAMILY, typename V>\n__device__ __forceinline__ void cad_store_stream(V* p, V v) {",
+         "__device__ __forceinline__ void cad_glds16_stream(const void* gsrc, uint32_t lds_base) {\n"
+         "#ifdef CAD_EMU\n    cad_glds16(gsrc, lds_base);\n#else\n    uint32_t keep;\n"
+         '    asm volatile("s_mov_b32 %0, m0\\n\\ts_mov_b32 m0, %2\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %1, off nt\\n\\ts_mov_b32 m0, %0"\n'
+         '                 : "=&s"(keep)\n                 : "v"(gsrc), "s"(lds_base)\n                 : "memory");\n#endif\n}\n'
+         "template <int FAMILY, typename V>\n__device__ __forceinline__ void cad_store_stream(V* p, V v) {"),
+        ("gemm.hip", "__ALL__cad_glds16(", "cad_glds16_stream("),
+        ("gemm_fp8.hip", "__ALL__cad_glds16(", "cad_glds16_stream("),
+    ],
     # ordinary stores everywhere (the state before csrc/cad_stream.h)
     "plain_stores": [("cad_stream.h", "#define CAD_NT_MASK 7", "#define CAD_NT_MASK 0")],
 }
@@ -36,7 +48,11 @@ def build(name):
     for fname, old, new in VARIANTS[name]:
         p = os.path.join(csrc, fname)
         s = open(p).read()
-        assert s.count(old) == 1, f"{name}: `{old[:60]}` occurs {s.count(old)} times in {fname}"
+        if old.startswith("__ALL__"):  # every occurrence (at least one)
+            old = old[len("__ALL__"):]
+            assert s.count(old) >= 1, f"{name}: `{old[:60]}` does not occur in {fname}"
+        else:
+            assert s.count(old) == 1, f"{name}: `{old[:60]}` occurs {s.count(old)} times in {fname}"
         open(p, "w").write(s.replace(old, new))
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
              f'-DCAD_SRC_HASH="exp-{name}"']
