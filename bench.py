@@ -52,15 +52,81 @@ def synthetic_batch(gen, B, L, device):
     return ids.to(device), labels.to(device)
 
 
+def host_topology():
+    """Physical cores of socket 0 (one hardware thread each) and the CPU model string, from sysfs / procfs.  The CPU baseline is pinned
+    to exactly these: with every hardware thread of a two-socket host in one OpenMP team the 1024-token problem of configs[0] measured
+    thread synchronisation across sockets, and swung 4x from box to box."""
+    cpus, seen = [], set()
+    allowed = sorted(os.sched_getaffinity(0))
+    for c in allowed:
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        if pkg == min_pkg(allowed) and (pkg, core) not in seen:
+            seen.add((pkg, core))
+            cpus.append(c)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cpus or allowed, model
+
+
+def min_pkg(allowed):
+    pk = []
+    for c in allowed:
+        try:
+            pk.append(int(open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id").read()))
+        except (OSError, ValueError):
+            pk.append(0)
+    return min(pk) if pk else 0
+
+
 def cpu_baseline(scan_L=131072):
+    """Runs cpu_baseline_worker in a fresh process pinned to the physical cores of one socket (OMP_NUM_THREADS = that count,
+    OMP_PROC_BIND=close, OMP_PLACES=cores, sched_setaffinity before any OpenMP runtime starts) and returns its JSON."""
+    import subprocess
+    cpus, model = host_topology()
+    env = dict(os.environ, OMP_NUM_THREADS=str(len(cpus)), OMP_PROC_BIND="close", OMP_PLACES="cores", MKL_NUM_THREADS=str(len(cpus)),
+               CAD_CPU_BASELINE_CPUS=",".join(map(str, cpus)), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(int(scan_L))], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, check=False)
+    if out.returncode != 0:
+        raise RuntimeError("cpu baseline worker failed: " + out.stderr.decode()[-400:])
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    res["cpu_model"] = model
+    return res
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def cpu_baseline_worker(scan_L=131072, reps_model=15, reps_scan=3):
     """the oracle (reference formulation, fp32, C/OpenMP scan + torch CPU GEMMs) on the host cores:
     (i) configs[0] = Caduceus-PS d_model=128 n_layer=4 seqlen=1024, batch 1, one full forward + backward -> tokens/s
-    (`value`); (ii) the selective-scan op alone at (B, E, L, N) = (1, 512, scan_L, 16), forward and backward -> GB/s of
-    the same algorithmic bytes the GPU roofline uses (fp32 on the CPU: s = 4)."""
+    (`value` = 1024 / the MEDIAN of `reps_model` timed repetitions after two warm-up passes); (ii) the selective-scan op alone at
+    (B, E, L, N) = (1, 512, scan_L, 16), forward and backward (median of `reps_scan`) -> GB/s of the same algorithmic bytes the GPU
+    roofline uses (fp32 on the CPU: s = 4)."""
+    cpus = [int(c) for c in os.environ.get("CAD_CPU_BASELINE_CPUS", "").split(",") if c]
+    if cpus:
+        os.sched_setaffinity(0, cpus)  # before torch / the oracle library start their OpenMP teams
+    import torch as th
+    if cpus:
+        th.set_num_threads(len(cpus))
     from caduceus_amd import CaduceusForMaskedLM
     from oracle import oracle_model as om
     from oracle import oracle_ops
-    torch.manual_seed(2222)
+    th.manual_seed(2222)
     d_model, n_layer, L = 128, 4, 1024
     cfgobj = make_config(d_model, n_layer)
     model = CaduceusForMaskedLM(cfgobj)  # parameter container only (CPU); arithmetic below is the oracle's
@@ -68,45 +134,49 @@ def cpu_baseline(scan_L=131072):
           for k, v in model.state_dict().items()}
     cfg = dict(rcps=True, fused_add_norm=True, rms_norm=True, norm_epsilon=1e-5, n_layer=n_layer, bidirectional=True,
                bidirectional_strategy="add")
-    ids, labels = synthetic_batch(torch.Generator().manual_seed(1), 1, L, "cpu")
+    ids, labels = synthetic_batch(th.Generator().manual_seed(1), 1, L, "cpu")
     om.set_scan_backend(oracle_ops.selective_scan_c)
+    times = []
     try:
-        reps, dt = 0, 0.0
-        while reps < 3 or (dt < 2.0 and reps < 50):  # first pass warms the thread pool; bounded to a few seconds
+        for rep in range(2 + reps_model):  # two warm-up passes (thread pools, allocator), then the timed ones
             t0 = time.perf_counter()
             out = om.masked_lm_forward(sd, ids, cfg, labels=labels, ignore_index=4)
             out["loss"].backward()
-            t1 = time.perf_counter() - t0
-            if reps > 0:
-                dt += t1
-            reps += 1
-        c1 = L * (reps - 1) / dt
+            if rep >= 2:
+                times.append(time.perf_counter() - t0)
     finally:
         om.set_scan_backend(None)
+    c1 = L / _median(times)
     # scan-op microbench (SURVEY 8d inputs: u, z, delta_raw, B, C ~ N(0,1); A = -(1..16); D = 1)
     E, N = 512, 16
-    g = torch.Generator().manual_seed(3)
-    r = lambda *sh: torch.randn(*sh, generator=g)
+    g = th.Generator().manual_seed(3)
+    r = lambda *sh: th.randn(*sh, generator=g)  # noqa: E731
     u, delta, z, Bm, Cm = r(1, E, scan_L), r(1, E, scan_L), r(1, E, scan_L), r(1, N, scan_L), r(1, N, scan_L)
-    A = -(torch.arange(1, N + 1).float().repeat(E, 1))
-    D, bias = torch.ones(E), r(E) - 4.0
+    A = -(th.arange(1, N + 1).float().repeat(E, 1))
+    D, bias = th.ones(E), r(E) - 4.0
     ins = [t.requires_grad_(True) for t in (u, delta, A, Bm, Cm, D, z, bias)]
     oracle_ops.selective_scan_c(*ins)  # warm-up
-    t0 = time.perf_counter()
-    y = oracle_ops.selective_scan_c(*ins)
-    tf = time.perf_counter() - t0
-    go = torch.randn(y.shape, generator=g)
-    t0 = time.perf_counter()
-    y.backward(go)
-    tb = time.perf_counter() - t0
-    cores = max(oracle_ops.num_threads(), torch.get_num_threads())
-    return {"value": c1, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"configs[0] Caduceus-PS d_model=128 n_layer=4 seqlen=1024 batch=1, full fwd+bwd x{reps - 1} "
-                      f"(fp32, oracle/oracle_model.py + oracle/cad_oracle.c OpenMP scan), {dt:.1f} s; "
-                      f"os.cpu_count()={os.cpu_count()}",
-            "scan_microbench": {"shape_BELN": [1, E, scan_L, N], "dtype": "f32", "fwd_s": tf, "bwd_s": tb,
-                                "fwd_GBps": (4 * E + 2 * N) * 4 * scan_L / tf / 1e9,
-                                "bwd_GBps": (7 * E + 4 * N) * 4 * scan_L / tb / 1e9}}
+    tfs, tbs = [], []
+    for _ in range(reps_scan):
+        t0 = time.perf_counter()
+        y = oracle_ops.selective_scan_c(*ins)
+        tfs.append(time.perf_counter() - t0)
+        go = th.randn(y.shape, generator=g)
+        t0 = time.perf_counter()
+        y.backward(go)
+        tbs.append(time.perf_counter() - t0)
+    tf, tb = _median(tfs), _median(tbs)
+    threads = max(oracle_ops.num_threads(), th.get_num_threads())
+    res = {"value": c1, "unit": "tokens/s", "cores": threads, "kind": "port",
+           "sample": f"configs[0] Caduceus-PS d_model=128 n_layer=4 seqlen=1024 batch=1, full fwd+bwd: median of {len(times)} "
+                     f"repetitions after 2 warm-up passes (fp32, oracle/oracle_model.py + oracle/cad_oracle.c OpenMP scan), "
+                     f"{sum(times):.1f} s timed; pinned to the {len(cpus) or threads} physical cores of one socket "
+                     f"(OMP_PROC_BIND=close, OMP_PLACES=cores); os.cpu_count()={os.cpu_count()}",
+           "rep_seconds": [round(t, 4) for t in times], "spread": (max(times) - min(times)) / _median(times),
+           "scan_microbench": {"shape_BELN": [1, E, scan_L, N], "dtype": "f32", "fwd_s": tf, "bwd_s": tb, "reps": reps_scan,
+                               "fwd_GBps": (4 * E + 2 * N) * 4 * scan_L / tf / 1e9,
+                               "bwd_GBps": (7 * E + 4 * N) * 4 * scan_L / tb / 1e9}}
+    print(json.dumps(res), flush=True)
 
 
 # instruction price of one (channel, position, state pair) element on one SIMD, ns (DESIGN.md section 3 "Floors": the per-pair-step
@@ -129,6 +199,9 @@ def pmc_quotable(pmc: dict, lib_version: str):
 
 
 def main():
+    if len(sys.argv) >= 2 and sys.argv[1] == "--cpu-baseline-worker":
+        cpu_baseline_worker(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -164,11 +237,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TEST HOOK (tests/test_bench_cli.py, CPU suite): CADUCEUS_BENCH_TEST_BACKEND=emu runs this very script -- rank / world handling,
+    # per-rank seeds, accumulation under no_sync(), the MAX all-reduce of the timing, the JSON line -- on CPU tensors with the kernels
+    # of the host emulator (tests/emu) and gloo, so that the N > 1 code path of bench.py has been executed before the driver
+    # launches it on an 8-GPU node.  Never a measurement: the line says data = "synthetic (host emulator: not a measurement)".
+    emu = os.environ.get("CADUCEUS_BENCH_TEST_BACKEND") == "emu"
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        from build_emu import build_emu
+        _lib.use_library_for_testing(build_emu())
+        dev = torch.device("cpu")
+        args.cpu_sample = 0
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("CADUCEUS_DP_FORCE_COLLECTIVE") == "1"
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
 
     torch.manual_seed(2222)  # configs/experiment/hg38/hg38.yaml:54; identical initial weights on every rank
     model = CaduceusForMaskedLM(make_config(args.d_model, args.n_layer, rcps=args.model == "ps")).to(dev).train()
@@ -179,7 +267,7 @@ def main():
         (no_decay if (n_.endswith("bias") or getattr(p, "_no_weight_decay", False) or "embedding" in n_) else decay
          ).append(p)
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=8e-3, betas=(0.9, 0.95), fused=True)
+                            lr=8e-3, betas=(0.9, 0.95), fused=True)  # (torch's fused AdamW also has a CPU implementation)
     amp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     gen = torch.Generator().manual_seed(2222 + rank)
     batches = [synthetic_batch(gen, args.batch, args.seqlen, dev) for _ in range(min(8, args.steps + args.warmup))]
@@ -194,7 +282,7 @@ def main():
 
     def micro(i, scale):
         ids, labels = batches[i % len(batches)]
-        with torch.autocast("cuda", dtype=amp, enabled=amp != torch.float32):
+        with torch.autocast(dev.type, dtype=amp, enabled=amp != torch.float32):
             out = model(ids, labels=labels)
         (out.loss * scale if scale != 1.0 else out.loss).backward()
         return out.loss
@@ -214,7 +302,8 @@ def main():
     def fence():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         loss = step(i)
@@ -257,7 +346,7 @@ def main():
         n_ops = args.n_layer * args.steps * accum
         for k in ("scan_fwd", "scan_bwd"):
             ms, n = prof[k]
-            if n:
+            if n and ms > 0:  # (the host emulator counts launches but has no device time)
                 kinds[k] = {"launches": n, "launches_per_op": n / n_ops, "avg_ms": ms / n_ops,
                             "achieved_GBps": alg[k] / (ms / n_ops * 1e-3) / 1e9, "algorithmic_bytes_per_launch": alg[k],
                             "total_ms": ms}
@@ -300,6 +389,8 @@ def main():
         # MFMA evidence for the dense projections (north_star): the in_proj GEMM of this workload, timed stand-alone
         proj = None
         try:
+            if emu:
+                raise RuntimeError("host emulator: no device timing")
             Tt = (2 if args.model == "ps" else 1) * args.batch * args.seqlen
             xx = torch.randn(Tt, args.d_model, device=dev, dtype=amp)
             ww = torch.randn(2 * E, args.d_model, device=dev, dtype=amp)
@@ -358,7 +449,7 @@ def main():
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": args.dtype + (" (in_proj: fp8 e4m3 MFMA, fp32 accumulate)" if args.fp8_proj else ""),
-            "data": "synthetic",
+            "data": "synthetic" + (" (host emulator: not a measurement)" if emu else ""),
             "config": {"workload": f"Caduceus-{args.model.upper() if args.model == 'ps' else 'Ph'} d_model={args.d_model} "
                                    f"n_layer={args.n_layer} seqlen={args.seqlen} rcps={'true' if args.model == 'ps' else 'false'} "
                                    f"MLM fwd+bwd+allreduce+AdamW, {args.batch} seq/GPU"

@@ -35,15 +35,23 @@ std::mutex g_mu;
 unsigned g_mask = 0;  // bit k: kind k is timed
 #ifndef CAD_EMU
 struct Rec {
-    int kind;
+    int kind, dev;
     hipEvent_t a, b;
 };
 std::vector<Rec> g_recs;
-std::vector<hipEvent_t> g_free;  // events of earlier measurements, reused: no hipEventCreate on the launch path after the first pass
-bool take_event(hipEvent_t* e) {
-    if (!g_free.empty()) {
-        *e = g_free.back();
-        g_free.pop_back();
+// events of earlier measurements, reused: no hipEventCreate on the launch path after the first pass.  One pool PER DEVICE: an event
+// belongs to the device it was created on and cannot be recorded on another device's stream (multi-GPU single process)
+std::vector<hipEvent_t> g_free[CAD_MAX_DEVICES];
+int cur_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= CAD_MAX_DEVICES) return -1;
+    return d;
+}
+bool take_event(int dev, hipEvent_t* e) {
+    if (dev < 0) return false;
+    if (!g_free[dev].empty()) {
+        *e = g_free[dev].back();
+        g_free[dev].pop_back();
         return true;
     }
     return hipEventCreate(e) == hipSuccess;
@@ -59,9 +67,10 @@ CadProfScope::CadProfScope(int k, void* s) : kind(k), stream(s), slot(-1) {
 #ifndef CAD_EMU
     Rec r;
     r.kind = k;
-    if (!take_event(&r.a)) return;
-    if (!take_event(&r.b)) {
-        g_free.push_back(r.a);
+    r.dev = cur_device();
+    if (!take_event(r.dev, &r.a)) return;
+    if (!take_event(r.dev, &r.b)) {
+        g_free[r.dev].push_back(r.a);
         return;
     }
     (void)hipEventRecord(r.a, (hipStream_t)s);
@@ -94,9 +103,16 @@ extern "C" int cad_prof_enable_kinds(unsigned mask) {
 extern "C" int cad_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
 #ifndef CAD_EMU
-    for (auto& r : g_recs) {  // (the caller has synchronised: cad_prof_read, or the stream)
-        g_free.push_back(r.a);
-        g_free.push_back(r.b);
+    for (auto& r : g_recs) {
+        // an event still pending (reset without a preceding read / synchronise) is destroyed, not recycled: a recycled pending
+        // event would make the next measurement it is used for wait on, or report, the old record
+        if (hipEventQuery(r.b) == hipSuccess) {
+            g_free[r.dev].push_back(r.a);
+            g_free[r.dev].push_back(r.b);
+        } else {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
     }
     g_recs.clear();
 #else

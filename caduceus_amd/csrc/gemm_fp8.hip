@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(cad_quant_fp8_args 
     for (int i = 0; i < EPL; ++i) m = fmaxf(m, fabsf(v[i]));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
-    const float scale = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;
+    // clamped like the weight-side quantiser (ops.quant_weight_fp8): a row whose max|x| is denormal-small must not turn 1 / scale into inf
+    const float scale = m > 0.f ? fmaxf(m * (1.0f / 448.0f), 1e-30f) : 1.0f;
     const float inv = 1.0f / scale;
     uint32_t* q = (uint32_t*)((uint8_t*)a.q + row * a.ldq + lane * EPL);
 #pragma unroll

@@ -178,6 +178,18 @@ def causal_conv1d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
 #   composition of the k maps per row in the row's own direction (a few element-wise launches on (E, SB * k, N) tensors),
 #   pass 2 (the full kernels) from the true entry states (h0 / dhT of the scan C-ABI).
 # The same carries and composition chain segments ACROSS ranks in caduceus_amd/seqpar.py.
+_CU_COUNT = None
+
+
+def _cu_count() -> int:
+    """Compute units of the current device (256 on MI355X), queried once; 256 without a device (host emulator)."""
+    global _CU_COUNT
+    if _CU_COUNT is None:
+        _CU_COUNT = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) \
+            if torch.cuda.is_available() else 256
+    return _CU_COUNT
+
+
 def lsplit_factor(E: int, SB: int, Lq: int, nsets: int) -> int:
     env = os.environ.get("CADUCEUS_AMD_LSPLIT", "")
     chunk = int(L.get_lib().cad_scan_chunk_len())
@@ -187,7 +199,7 @@ def lsplit_factor(E: int, SB: int, Lq: int, nsets: int) -> int:
     ok = lambda k: Lq % (k * chunk) == 0 and Lq // k >= 8 * chunk
     wgs = ((E + 7) // 8) * SB * nsets
     k = 1
-    while wgs * 2 * k <= 256 and ok(2 * k):
+    while wgs * 2 * k <= _cu_count() and ok(2 * k):
         k *= 2
     return k
 
@@ -470,6 +482,9 @@ class _LmHead(torch.autograd.Function):
         loss = acc[0] / acc[1] if labels is not None else acc[0]
         ctx.save_for_backward(hidden, w, comp, lab, logits, acc)
         ctx.meta = (ignore_index, weight.dtype, labels is not None)
+        # an output nobody differentiated reaches backward as None instead of a zero-filled (rows, V) fp32 tensor the kernel would
+        # allocate and read (training uses the loss alone)
+        ctx.set_materialize_grads(False)
         return logits, loss
 
     @staticmethod
@@ -481,7 +496,7 @@ class _LmHead(torch.autograd.Function):
         lib = L.get_lib()
         use_loss = has_labels and dloss is not None
         if (use_loss or dlogits is not None) and hidden.dtype in (torch.float32, torch.bfloat16) and \
-                lib.cad_lm_head_bwd_supported(int(D), int(V)):
+                lib.cad_lm_head_bwd_supported(int(D), int(V)) and hidden.data_ptr() % 16 == 0:  # (kernel: 16-byte vector accesses)
             # one launch on the matrix cores: softmax gradient, d hidden of both strands, dW partial slots (cad_lm_head_bwd)
             rows = hidden.numel() // (S * D)
             dh = torch.empty_like(hidden)

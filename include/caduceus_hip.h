@@ -313,12 +313,14 @@ int cad_proj_wx_thin_supported(int M, int K, int64_t T);
 /* cad_proj_wx_wgrad: the thin-M / deep-K product  out (M, T) = W (M, K) . X (K, T)  AND, from the same single pass over X, the weight
  * gradient  dW (K, M) = X (K, T) . Y (M, T)^T  -- d(dt_lr) = W_dt^T . d(delta) together with dW_dt = d(delta) . dt_lr^T of the dt_proj
  * backward (both stream the (d_inner, T) tensor d(delta); mamba_inner_fn's backward reached from modeling_caduceus.py:128,130).
- * M in {16, 32}, K in {256, 512} (cad_proj_wx_wgrad_supported), T % 8 == 0, bf16.  wg_partials: cad_proj_wx_wgrad_partials(T) slots of
+ * M in {16, 32}, K in {256, 512} (cad_proj_wx_wgrad_supported), T >= 128 and T % 128 == 0 (whole 128-token blocks: the kernel has no
+ * tail block), bf16.  wg_partials: cad_proj_wx_wgrad_partials(T) slots of
  * (K, M) fp32, one per workgroup, WRITTEN (no zeroing needed); dW = the sum over the slots (fixed order: deterministic). */
 int cad_proj_wx_wgrad(const cad_proj_args* a, void* stream);
 int cad_proj_wx_wgrad_supported(int M, int K, int64_t T);
 /* With W == NULL and out == NULL the same entry point computes the weight gradient alone, for any M <= 64
- * (cad_proj_wgrad_only_supported): dW_x = xc . d(dbc)^T of the x_proj backward (M = dt_rank + 2 d_state). */
+ * (cad_proj_wgrad_only_supported; the same T >= 128, T % 128 == 0): dW_x = xc . d(dbc)^T of the x_proj backward
+ * (M = dt_rank + 2 d_state). */
 int cad_proj_wgrad_only_supported(int M, int K, int64_t T);
 int cad_proj_wx_wgrad_partials(int64_t T);
 

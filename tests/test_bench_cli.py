@@ -1,0 +1,61 @@
+"""bench.py's own N > 1 code path, executed on CPU: the driver's launch line (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`) with the kernels of the host emulator and gloo
+(CADUCEUS_BENCH_TEST_BACKEND=emu, a test hook inside bench.py).  Checks what the 8-GPU run relies on: rank / world handling, one JSON
+line from rank 0 only, whole-job token accounting, accumulation micro-steps under no_sync(), the MAX all-reduce of the timing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, extra, tmp_path):
+    env = dict(os.environ, CADUCEUS_BENCH_TEST_BACKEND="emu", OMP_NUM_THREADS="2", CAD_EMU_THREADS="2")
+    tiny = ["--steps", "2", "--warmup", "1", "--seqlen", "256", "--d-model", "32", "--n-layer", "2", "--dtype", "fp32"]
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *tiny, *extra]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *tiny, *extra]
+    out = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines  # rank 0 alone prints, exactly one line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("nproc,extra,accum,scaling", [
+    (2, [], 1, "weak"),                        # configs[3]'s launch shape: one sequence per rank and step
+    (2, ["--global-batch", "4"], 2, "strong"),  # the reference's fixed global batch: 2 micro-steps per rank, first under no_sync()
+])
+def test_bench_two_ranks_over_gloo(tmp_path, nproc, extra, accum, scaling):
+    line = _run(nproc, extra, tmp_path)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == nproc and line["steps"] == 2 and line["warmup"] == 1
+    assert line["scaling"] == scaling and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["config"]["parallelism"] == f"dp{nproc}" and line["config"]["accumulate_grad_batches"] == accum
+    assert line["config"]["global_batch"] == nproc * accum
+    # whole-job aggregate: tokens of ALL ranks and micro-steps over the MAX-over-ranks time
+    tokens = 256 * nproc * 2 * accum
+    assert abs(line["value"] - tokens / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert "not a measurement" in line["data"]
+    assert line["config"]["final_loss"] == line["config"]["final_loss"]  # finite (not NaN)
+
+
+def test_bench_single_rank_line(tmp_path):
+    line = _run(1, [], tmp_path)
+    assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "dp1" and line["scaling"] == "weak"

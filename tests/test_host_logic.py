@@ -165,3 +165,41 @@ def test_bench_quotes_a_counter_profile_only_for_the_profiled_scan_sources():
     # the committed profile is quotable for the committed sources
     committed = json.load(open(os.path.join(ROOT, "profiles", "r03_scan_pmc.json")))
     assert bench.pmc_quotable(committed, cur), "profiles/r03_scan_pmc.json does not belong to the scan sources in the tree"
+
+
+# ---- the reference's import name (north_star: "train.py and the HF AutoModel path load it unchanged") ---------------------
+REGISTRY_MODEL_STRING = "caduceus.modeling_caduceus.CaduceusForMaskedLM"       # /root/reference/src/utils/registry.py:29
+HYDRA_CONFIG_TARGET = "caduceus.configuration_caduceus.CaduceusConfig"        # /root/reference/configs/model/caduceus.yaml:4
+
+
+def _locate(dotted):
+    """What the reference does with such a string (src/utils/registry.py + src/utils/config.py `instantiate`: hydra.utils.get_class ==
+    import the module part, getattr the last component)."""
+    import importlib
+    mod, name = dotted.rsplit(".", 1)
+    return getattr(importlib.import_module(mod), name)
+
+
+def test_reference_import_name_resolves_to_this_engine():
+    import os
+    ref = "/root/reference"
+    if os.path.isdir(ref):  # build container: take the literal strings from the reference's own files (absent on the GPU box)
+        reg = open(os.path.join(ref, "src", "utils", "registry.py")).read()
+        yml = open(os.path.join(ref, "configs", "model", "caduceus.yaml")).read()
+        assert f'"caduceus_lm": "{REGISTRY_MODEL_STRING}"' in reg
+        assert f"_target_: {HYDRA_CONFIG_TARGET}" in yml
+    import caduceus
+    import caduceus_amd
+    assert _locate(REGISTRY_MODEL_STRING) is caduceus_amd.CaduceusForMaskedLM
+    assert _locate(HYDRA_CONFIG_TARGET) is caduceus_amd.CaduceusConfig
+    # not copies: the same module objects under both names, the reference's package exports (caduceus/__init__.py:5-7) included
+    for sub in ("configuration_caduceus", "modeling_caduceus", "modeling_rcps", "tokenization_caduceus"):
+        assert getattr(caduceus, sub) is getattr(caduceus_amd, sub)
+        import importlib
+        assert importlib.import_module(f"caduceus.{sub}") is getattr(caduceus_amd, sub)
+    for name in ("CaduceusConfig", "Caduceus", "CaduceusForMaskedLM", "CaduceusForSequenceClassification", "CaduceusTokenizer"):
+        assert getattr(caduceus, name) is getattr(caduceus_amd, name)
+    # the instantiation train.py performs: registry class + yaml config -> a model with the reference's state-dict keys
+    cfg, sd, _ = load_golden_model("ps_fused")
+    model = _locate(REGISTRY_MODEL_STRING)(_locate(HYDRA_CONFIG_TARGET)(**cfg))
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
