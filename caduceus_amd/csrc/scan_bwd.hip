@@ -68,6 +68,18 @@ struct ScanBwdSets {
 #endif
 
 static_assert(SC_CHUNK == SC_STATE_STEP, "backward chunk = one saved-state slot");
+// Only S = 8 items per lane is a supported backward.  S = 4 (a 128-VGPR build: four waves per SIMD) was asked for as an experiment
+//  and is refused here instead of left as an instantiation that faults on the device: (i) at one sequence per GPU
+// a BiMamba layer has E x 2 strands x 2 sets = 2048 channel-row waves = two per SIMD, so a four-wave build only fills half the CUs
+// (or needs 16-channel workgroups: 128 workgroups on 256 CUs); (ii) the two wave scans, the staging and the flush are per (lane
+// segment, pair), so halving the segment doubles ~40 % of the instructions per element (the forward built that way measured -15 %,
+// profiles/r03_occupancy_experiments.txt); (iii) the packed slab / MFMA flush / 16-byte LDS-DMA vectors are laid out for 8 items.
+static_assert(SC_S_BWD == 8, "the backward scan is written for 8 items per lane (see the comment above)");
+// -DSC_BWD_UNROLL_NP=8: A/B instantiation with the pair loop fully unrolled for d_state = 16 (compile-time pair index: lane
+// selections become immediates, the tile-buffer parity and the `more` / staging conditions fold)
+#ifndef SC_BWD_UNROLL_NP
+#define SC_BWD_UNROLL_NP 0
+#endif
 static_assert(SC_W == 4 || SC_W == 8, "staging needs >= 256 threads; the flush mapping is written for 256 / 512");
 
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1])); }
@@ -75,7 +87,7 @@ __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0
 // CO = carry-only instantiation (cad_scan_bwd_args.carry_only, pass 1 of an L-split backward): the reverse recurrence of the
 // state gradient alone -- exp, C * dy, one chain per item and state, the reverse wave scan -- and dh0 as its only output.  A
 // separate instantiation, so the full kernel carries none of its branches (measured: +5 % when they were run-time branches).
-template <typename T, bool VEC, bool CO>
+template <typename T, bool VEC, bool CO, int NPC = 0>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][wave][dB,dC][ACC_TILE] contributions
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const int e = act ? e_raw : a.E - 1;
     const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
     const int64_t L = a.L, SB = a.SB;
-    const int N = a.N, NP = (N + 1) >> 1;
+    const int N = NPC ? 2 * NPC : a.N, NP = NPC ? NPC : (a.N + 1) >> 1;  // NPC: compile-time pair count (the launcher checks N)
     const int64_t row_off = ((int64_t)e * SB + sb) * L;
     const T* u_row = (const T*)a.u + row_off;
     const T* d_row = (const T*)a.delta + row_off;
@@ -321,8 +333,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
         };
         SC_TIME(1);  // chunk prologue: unpack, gate, softplus
+#if SC_BWD_UNROLL_NP
+#pragma unroll
+#endif
         for (int np = 0; np < NP; ++np, ++tix) {
-            const int buf = tix & 1;
+            const int buf = (NPC && (NPC % 2) == 0) ? (np & 1) : (tix & 1);  // an even pair count: the parity restarts with every chunk
             const bool more = (np + 1 < NP) || (c > 0);
             if (more) {
                 const int nn = (np + 1 < NP) ? 2 * (np + 1) : 0;
@@ -763,7 +778,10 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
                          (pref ? PRE_BYTES : 0);
 #define SC_BWD_LAUNCH(T, V)                                                                  \
     do {                                                                                     \
-        if (a->carry_only) {                                                                 \
+        if (SC_BWD_UNROLL_NP && !a->carry_only && V && sizeof(T) == 2 && a->N == 2 * SC_BWD_UNROLL_NP) { \
+            SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP>), shmem);             \
+            CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP>), grid, block, shmem, stream, ks); \
+        } else if (a->carry_only) {                                                          \
             SC_BIG_LDS((scan_bwd_kernel<T, V, true>), shmem);                                \
             CAD_LAUNCH((scan_bwd_kernel<T, V, true>), grid, block, shmem, stream, ks);       \
         } else {                                                                             \

@@ -36,6 +36,11 @@
 #endif
 #define SC_STATE_STEP (64 * SC_S_BWD)   // positions between saved running states = the backward's chunk
 // timing experiments only (WRONG results): what does a mechanism cost?  (tools/ab_train_scan.sh over -DSC_WHATIF=... builds)
+// SC_WHATIF_ARITH_ONLY = the backward's "stripped timing build" (VERDICT r3 item 1): no global stores, no dB/dC slab / flush, no B/C
+// tile loads / conversion / LDS stores / reads, no workgroup barrier -- what is left is the input stream of the item vectors and the
+// arithmetic of the recurrence and its gradients (prologue, exp, serial chains, both wave scans, gradient loop, dA sums, epilogue)
+// at the same launch shape, register count and power state.  Kernel time / that time is quoted in bench.py's `roofline`.
+#define SC_WHATIF_ARITH_ONLY (2 | 32 | 64 | 2048 | 4096 | 8192)
 #ifndef SC_WHATIF
 #define SC_WHATIF 0
 #endif
@@ -656,6 +661,7 @@ __device__ __forceinline__ void sc_stage_seek(StageCtx<T>& c, int64_t base, int6
 template <typename T, int S>
 __device__ __forceinline__ void sc_stage_issue(StageRegs<T, SC_SV(S)>& r, const StageCtx<T>& c, int n0, int N) {
     if (!c.on) return;
+    if (SC_WHATIF & 8192) return;  // (timing experiment: no B / C tile loads at all)
     const bool two = n0 + 1 < N;
     const T* p = c.cur + n0 * c.row_stride;  // n0 < N always
     sc_async_load(r.s0, p);

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
                 SC_FWD_ADVANCE();
             }
             SC_TIME(5);  // staging store
-            if (((tix + 1) & (AHEAD - 1)) == 0) __syncthreads();
+            if (((tix + 1) & (AHEAD - 1)) == 0 && !(SC_WHATIF & 2)) __syncthreads();
             SC_TIME(6);  // barrier
         }
         if constexpr (MO) continue;  // no output of a map-only pass
