@@ -57,7 +57,7 @@ def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = 
         return out
     objdir = os.path.join(HERE, "build", os.path.basename(out))
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-pass-failed"]
     flags += [f"-D{d}" for d in defines] + list(extra_flags) + [f'-DCAD_SRC_HASH="{source_hash(defines)}"']
     procs = []
     for src in sources():

@@ -369,6 +369,264 @@ __global__ __launch_bounds__(CV_THREADS, CV_BWD_WAVES) void conv1d_bwd_kernel(Co
     }
 }
 
+
+__device__ __forceinline__ void gp_wait_dma_conv() {
+#ifndef CAD_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// ======================================================================================================================
+// Fused backward:  conv1d backward  +  the x_proj input gradient  +  the x_proj weight gradient.
+//   d(xc) = du + W_x^T . d(dbc)      (the x_proj nn.Linear of mamba_inner_fn feeds on the conv output xc: its input gradient is
+//                                     ADDED to the scan's du before the conv backward; used to be cad_proj_wx with an addend:
+//                                     read du, write du -- 536 MB per parameter set that existed only to be read again here)
+//   dW_x  = d(dbc) . xc^T             (used to be cad_proj_wx_wgrad's weight-gradient stage: re-read the 268 MB of xc per set;
+//                                     here xc is RECOMPUTED from x -- the conv backward evaluates conv(x) and its sigmoid anyway)
+//   dx, dw, dbias                     exactly as conv1d_bwd_kernel (same tap order, same rounding points)
+// One workgroup (8 waves) owns CX_CB = 32 channels and walks 512-position tiles (496 useful, as above) of its rows.  Per tile and
+// parameter set:  (1) the (M = dt_rank + 2 d_state, 512) tile of d(dbc) comes in by LDS-DMA (one 1 KB row per instruction, rows
+// padded by 32 bytes: the transposing reads of eight consecutive rows hit distinct banks), a tile ahead of its use;  (2) P = W_x^T .
+// d(dbc) for the 32 x 512 tile on the matrix cores (A = d(dbc) fragments by transposing reads, B = W_x^T fragments from global: a D
+// lane holds four consecutive positions of one channel), rounded to bf16 into a [channel][position] staging tile -- the same product,
+// instruction and rounding as cad_proj_wx;  (3) every wave runs the conv backward of 4 of the channels, one after the other, on
+// d(xc) = bf16(du + P) and writes xc (bf16, zero on halo lanes) over P in the staging tile;  (4) dW_x[channel][m] += xc_tile .
+// d(dbc)_tile^T on the matrix cores (both operands position-contiguous: plain 16-byte fragment reads), accumulated in registers over
+// all tiles of the workgroup, one (E, M) fp32 partial slot per token group at the end.  dx of both sets is summed in registers.
+#define CX_WAVES 8
+#define CX_CPW 4                                  // channels per wave (sequential)
+#define CX_CB (CX_WAVES * CX_CPW)                 // channels per workgroup
+#define CX_TW 512                                 // positions per tile (64 lanes x 8); CV_WAVE_POS = 496 of them useful
+#define CX_ROWB (CX_TW * 2 + 32)                  // bytes per LDS row of the d(dbc) tile and of the staging tile
+#define CX_MMAX 64
+
+struct ConvXprojSets {
+    cad_conv_xproj_bwd_args s[CV_MAXSETS];
+};
+
+template <int NSETS>
+__global__ __launch_bounds__(64 * CX_WAVES, 2) void conv_xproj_bwd_kernel(ConvXprojSets sets) {
+    typedef bf16_t T;
+    CAD_DYN_SMEM(char, smem);
+    const cad_conv_xproj_bwd_args& a0 = sets.s[0];
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const int g = lane >> 4, jl = lane & 15;
+    const int64_t L = a0.L, SB = a0.SB;
+    const int M = a0.M, MB = (M + 15) >> 4;
+    const int cb0 = blockIdx.x * CX_CB;           // first channel of this workgroup
+    const uint32_t tpr = (uint32_t)((L + CV_WAVE_POS - 1) / CV_WAVE_POS);
+    const uint32_t nvt = (uint32_t)SB * tpr;
+    const int mrows = MB * 16;                    // rows of the d(dbc) tile (rows >= M: never read as data)
+    char* dtile[CV_MAXSETS];
+    dtile[0] = smem;
+    dtile[1] = smem + (size_t)mrows * CX_ROWB;
+    char* stage = smem + (size_t)NSETS * mrows * CX_ROWB;  // [CX_CB channels][CX_ROWB]
+    const float useful = (lane >= 1 && lane <= 62) ? 1.f : 0.f;
+
+    auto tile_pos = [&](uint32_t v, int64_t& sb, int64_t& l_first) {  // row and first LOADED position of virtual tile v
+        const uint32_t r = v / tpr;
+        sb = r;
+        l_first = (int64_t)(v - r * tpr) * CV_WAVE_POS - CV_VEC;
+    };
+    // LDS-DMA of the d(dbc) tile of set s for virtual tile v: row m by wave (m % 8), lane = 16-byte piece (8 positions); pieces outside
+    // the row re-read valid data from a clamped address (their products are masked in the conv stage, their xc is zero)
+    auto issue_dtile = [&](int s, uint32_t v) {
+        int64_t sb, lf;
+        tile_pos(v, sb, lf);
+        int64_t l = lf + (int64_t)lane * CV_VEC;
+        l = l < 0 ? 0 : l;
+        l = l + CV_VEC <= L ? l : L - CV_VEC;
+        const T* base = (const T*)sets.s[s].ddbc + sb * L + l;
+        for (int m = wave; m < M; m += CX_WAVES)  // wave-uniform
+            cad_glds16(base + (int64_t)m * sets.s[s].ld_ddbc, cad_uniform((int)(cad_lds_off(dtile[s]) + m * CX_ROWB)));
+    };
+    const uint32_t v0 = blockIdx.y, vstep = gridDim.y;
+    if (v0 >= nvt) return;  // (the launcher never starts such a workgroup)
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) issue_dtile(s, v0);
+
+    float part[CX_CPW][NSETS][CV_KMAX + 1];       // per-lane partial sums of dw4[0..3], dbias of this wave's channels
+#pragma unroll
+    for (int c = 0; c < CX_CPW; ++c)
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+            for (int m = 0; m <= CV_KMAX; ++m) part[c][s][m] = 0.f;
+    // dW_x accumulators: the (channel block, m block) tiles of the (32, M) result are dealt to the waves -- wave j owns tile
+    // (cbk, mb) = (j / MB, j % MB) over ALL 512 positions of every tile (2 MB <= 8 jobs), so a wave carries ONE accumulator tile per
+    // set and nothing has to be exchanged at the end
+    f32x4 dwx[NSETS];
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) dwx[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool wx_job = wave < 2 * MB;            // wave-uniform
+    const int wx_cbk = wx_job ? wave / MB : 0, wx_mb = wx_job ? wave % MB : 0;
+    int wx_mr = wx_mb * 16 + jl;
+    wx_mr = wx_mr < M ? wx_mr : M - 1;            // rows >= M: valid data, their columns are never stored
+
+    for (uint32_t v = v0; v < nvt; v += vstep) {
+        int64_t sb, lf;
+        tile_pos(v, sb, lf);
+        const int64_t l0 = lf + (int64_t)lane * CV_VEC;   // this lane's 8 positions
+        const bool inside = l0 >= 0 && l0 < L;             // (L % 8 == 0: a vector lies inside or outside)
+        float o[CX_CPW][CV_VEC];                           // dx of this wave's channels, summed over the sets
+#pragma unroll
+        for (int c = 0; c < CX_CPW; ++c)
+#pragma unroll
+            for (int j = 0; j < CV_VEC; ++j) o[c][j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            const cad_conv_xproj_bwd_args& a = sets.s[s];
+            const int rev = sb < a.split ? a.rev_lo : a.rev_hi;  // wave-uniform: the tile's row
+            // (1) this set's d(dbc) tile has landed: this wave's share, then everybody's (the barrier also orders the previous
+            // user of the staging tile -- the dW_x stage of the set before -- ahead of the P product below)
+            gp_wait_dma_conv();
+            __syncthreads();
+            // (2) P = W_x^T . d(dbc): wave w takes the 16-position sub-blocks 4 w .. 4 w + 3 of both 16-channel blocks
+            {
+                u32x4 wfr[2][2];  // B fragments: channel cb0 + 16 cbk + jl, k = 32 ks + 8 g .. + 7 of W_x^T (zero beyond M)
+#pragma unroll
+                for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int k0 = ks * 32 + g * 8;
+                        u32x4 w4 = {0u, 0u, 0u, 0u};
+                        if (k0 + 8 <= M) w4 = *(const u32x4*)((const T*)a.wxT + (int64_t)(cb0 + cbk * 16 + jl) * a.ldw + k0);
+                        wfr[cbk][ks] = w4;
+                    }
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int q = wave * 4 + qq;
+                    u32x4 xf[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int k0 = ks * 32 + g * 8;
+                        // rows k0 .. k0 + 7 exist for k0 + 8 <= M; the other 16-lane groups read rows 0 .. 7 instead (every lane of the
+                        // wave takes part in a transposing read) and supply zeros
+                        const bool have = k0 + 8 <= M;
+                        const int r0 = (have ? k0 : 0) + (jl >> 2);
+                        const char* p0 = dtile[s] + r0 * CX_ROWB + q * 32 + (jl & 3) * 8;
+                        const u32x2 lo = cad_lds_read_tr16(p0), hi = cad_lds_read_tr16(p0 + 4 * CX_ROWB);
+                        const uint32_t km = have ? 0xFFFFFFFFu : 0u;
+                        xf[ks] = u32x4{lo[0] & km, lo[1] & km, hi[0] & km, hi[1] & km};
+                    }
+#pragma unroll
+                    for (int cbk = 0; cbk < 2; ++cbk) {
+                        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) d = cad_mfma_16x16x32_bf16(xf[ks], wfr[cbk][ks], d);
+                        u32x2 pk;
+                        pk[0] = cad_pack_bf16x2_safe(d[0], d[1]);
+                        pk[1] = cad_pack_bf16x2_safe(d[2], d[3]);
+                        *(u32x2*)(stage + (cbk * 16 + jl) * CX_ROWB + (q * 16 + g * 4) * 2) = pk;
+                    }
+                }
+            }
+            __syncthreads();  // the whole P tile is in the staging tile
+            // (3) conv backward of this wave's channels on d(xc) = bf16(du + P); xc goes back into the staging tile
+#pragma unroll
+            for (int c = 0; c < CX_CPW; ++c) {
+                const int cl = wave * CX_CPW + c, e = cb0 + cl;
+                const int64_t row = (int64_t)e * SB + sb;
+                float W4[CV_KMAX];
+                load_w4(a.w, e, a.K, W4);
+                const float bias = a.bias ? a.bias[e] : 0.f;
+                const CvRaw<T> rx = load8_raw<T, true>((const T*)a.x + row * L, l0, L);
+                const CvRaw<T> rdu = load8_raw<T, true>((const T*)a.du + row * L, l0, L);
+                char* srow = stage + cl * CX_ROWB + lane * 16;
+                const u32x4 pv = *(const u32x4*)srow;
+                float own[CV_VEC], xe[CV_VEC + 2 * CV_HALO], gg[CV_VEC], dpre[CV_VEC], dpe[CV_VEC + 2 * CV_HALO], xcv[CV_VEC];
+                cvt8<T, true>(rx, l0, L, own);
+#pragma unroll
+                for (int j = 0; j < CV_VEC / 2; ++j) {  // bf16(du + bf16 product), element-wise on the packed pairs (as cad_proj_wx)
+                    const float lo = cad_bits2f(pv[j] << 16) + cad_bits2f(rdu.w[j] << 16);
+                    const float hi = cad_bits2f(pv[j] & 0xFFFF0000u) + cad_bits2f(rdu.w[j] & 0xFFFF0000u);
+                    const uint32_t pk = cad_pack_bf16x2(lo, hi);
+                    gg[2 * j] = inside ? cad_bits2f(pk << 16) : 0.f;
+                    gg[2 * j + 1] = inside ? cad_bits2f(pk & 0xFFFF0000u) : 0.f;
+                }
+                halo_window(own, xe);
+                auto body = [&](auto dir) {
+                    constexpr int REV = decltype(dir)::value;
+#pragma unroll
+                    for (int j = 0; j < CV_VEC; ++j) {
+                        const float acc = conv4<REV>(W4, xe + j, bias);
+                        const float sg = cad_sigmoid(acc);
+                        xcv[j] = acc * sg;                              // = the forward's xc (same operations, same rounding below)
+                        dpre[j] = gg[j] * sg * (1.f + acc * (1.f - sg));
+                    }
+                    halo_window(dpre, dpe);
+#pragma unroll
+                    for (int j = 0; j < CV_VEC; ++j) {
+                        o[c][j] += conv4<!REV>(W4, dpe + j, 0.f);
+                        const float dm = dpre[j] * useful;
+#pragma unroll
+                        for (int k = 0; k < CV_KMAX; ++k) part[c][s][k] += dm * xe[j + (REV ? (CV_TAPS - 1 - k) : k)];
+                        part[c][s][CV_KMAX] += dm;
+                    }
+                };
+                if (rev) body(DirTag<1>{}); else body(DirTag<0>{});
+                const bool keep = inside && useful != 0.f;  // halo lanes and positions outside the row contribute nothing to dW_x
+                u32x4 xo;
+#pragma unroll
+                for (int j = 0; j < CV_VEC / 2; ++j) xo[j] = keep ? cad_pack_bf16x2(xcv[2 * j], xcv[2 * j + 1]) : 0u;
+                *(u32x4*)srow = xo;
+                if (s == NSETS - 1 && useful != 0.f) store8v<T, true>((T*)a0.dx + row * L, l0, L, o[c]);
+            }
+            __syncthreads();  // xc of all 32 channels is in the staging tile
+            // (4) dW_x[channel][m] += xc . d(dbc)^T: this wave's (channel block, m block) tile over the 512 positions (16 k steps)
+            if (wx_job) {
+#pragma unroll 4
+                for (int ks = 0; ks < CX_TW / 32; ++ks) {
+                    const int tb = (ks * 32 + g * 8) * 2;  // byte offset of this lane's 8 positions inside a tile row
+                    const u32x4 af = *(const u32x4*)(stage + (wx_cbk * 16 + jl) * CX_ROWB + tb);
+                    const u32x4 bfr = *(const u32x4*)(dtile[s] + wx_mr * CX_ROWB + tb);
+                    dwx[s] = cad_mfma_16x16x32_bf16(af, bfr, dwx[s]);
+                }
+            }
+            // this set's d(dbc) tile and the staging tile are free once every wave is past (4): the next tile's DMA goes out behind
+            // a barrier, under the other set's / the next tile's arithmetic
+            __syncthreads();
+            if (v + vstep < nvt) issue_dtile(s, v + vstep);
+        }
+    }
+    // ---- per-channel conv gradients: wave sums, a handful of atomics per channel and workgroup (as conv1d_bwd_kernel) ----
+#pragma unroll
+    for (int c = 0; c < CX_CPW; ++c) {
+        const int e = cb0 + wave * CX_CPW + c;
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            const cad_conv_xproj_bwd_args& a = sets.s[s];
+#pragma unroll
+            for (int m = 0; m <= CV_KMAX; ++m) {
+                float t = part[c][s][m];
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) t += __shfl_xor(t, sh);
+                if (lane == 0 && t != 0.f) {
+                    if (m < CV_KMAX) {
+                        const int k = m - (CV_KMAX - a.K);  // w[k] lives in w4[k + 4 - K]
+                        if (k >= 0) atomicAdd(&a.dw[e * a.K + k], t);
+                    } else if (a.dbias) {
+                        atomicAdd(&a.dbias[e], t);
+                    }
+                }
+            }
+        }
+    }
+    // ---- dW_x: D layout = lane (column m = 16 mb + jl, rows = channels 16 cbk + 4 g + r); one (32, M) block of this token group's slot
+    if (wx_job) {
+        const int m = wx_mb * 16 + jl;
+        if (m < M) {
+#pragma unroll
+            for (int s = 0; s < NSETS; ++s) {
+                float* slot = sets.s[s].dwx_partials + ((int64_t)blockIdx.y * sets.s[s].E + cb0 + wx_cbk * 16 + g * 4) * M + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slot[(int64_t)r * M] = dwx[s][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cad_conv1d_fwd_multi(const cad_conv1d_args* sets, int nsets, void* stream) {
@@ -463,3 +721,67 @@ extern "C" int cad_conv1d_bwd_multi(const cad_conv1d_bwd_args* sets, int nsets, 
 }
 
 extern "C" int cad_conv1d_bwd(const cad_conv1d_bwd_args* a, void* stream) { return cad_conv1d_bwd_multi(a, 1, stream); }
+
+
+// ---- fused backward: launcher -----------------------------------------------------------------------------------------------
+extern "C" int cad_conv_xproj_bwd_supported(int E, int K, int M, int64_t SB, int64_t L) {
+    return E > 0 && (E % CX_CB) == 0 && K >= 1 && K <= CV_KMAX && M >= 8 && M <= CX_MMAX && (M % 8) == 0 && SB >= 1 && L >= CV_VEC &&
+           (L % CV_VEC) == 0 && SB * ((L + CV_WAVE_POS - 1) / CV_WAVE_POS) < (1LL << 31);
+}
+// token groups = partial slots of dW_x: enough workgroups for every CU, never more than virtual tiles
+extern "C" int cad_conv_xproj_bwd_partials(int E, int64_t SB, int64_t L) {
+    const int64_t nvt = SB * ((L + CV_WAVE_POS - 1) / CV_WAVE_POS);
+    const int cbs = E / CX_CB > 0 ? E / CX_CB : 1;
+    int64_t gy = (256 + cbs - 1) / cbs;
+    if (gy > nvt) gy = nvt;
+    if (gy < 1) gy = 1;
+    return (int)gy;
+}
+
+extern "C" int cad_conv_xproj_bwd_multi(const cad_conv_xproj_bwd_args* sets, int nsets, void* stream) {
+    CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= CV_MAXSETS);
+    ConvXprojSets ks;
+    for (int i = 0; i < nsets; ++i) {
+        const cad_conv_xproj_bwd_args* a = &sets[i];
+        CAD_CHECK_ARG(a->x && a->w && a->du && a->ddbc && a->wxT && a->dx && a->dw && a->dwx_partials);
+        CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB);
+        CAD_CHECK_ARG(a->x == sets[0].x && a->dx == sets[0].dx && a->E == sets[0].E && a->SB == sets[0].SB && a->L == sets[0].L &&
+                      a->M == sets[0].M && a->dtype == sets[0].dtype);
+        CAD_CHECK_ARG(a->ld_ddbc >= a->SB * a->L && (a->ld_ddbc % 8) == 0 && a->ldw >= a->M && (a->ldw % 8) == 0);
+        CAD_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->du | (uintptr_t)a->ddbc | (uintptr_t)a->wxT | (uintptr_t)a->dx) % 16) == 0);
+        ks.s[i] = *a;
+    }
+    for (int i = nsets; i < CV_MAXSETS; ++i) ks.s[i] = sets[0];
+    const cad_conv_xproj_bwd_args* a = &sets[0];
+    if (a->dtype != CAD_BF16 || !cad_conv_xproj_bwd_supported(a->E, a->K, a->M, a->SB, a->L)) return CAD_ERR_UNSUPPORTED;
+    for (int i = 0; i < nsets; ++i)
+        if (sets[i].K < 1 || sets[i].K > CV_KMAX) return CAD_ERR_UNSUPPORTED;
+    CadProfScope prof(3, stream);
+    const int mrows = (a->M + 15) / 16 * 16;
+    const size_t lds = (size_t)nsets * mrows * CX_ROWB + (size_t)CX_CB * CX_ROWB;
+    dim3 grid((unsigned)(a->E / CX_CB), (unsigned)cad_conv_xproj_bwd_partials(a->E, a->SB, a->L)), block(64 * CX_WAVES);
+#if !defined(CAD_EMU)
+#define CX_BIG_LDS(kern)                                                                                                     \
+    do {                                                                                                                     \
+        static size_t cur[CAD_MAX_DEVICES] = {0};                                                                            \
+        int dev_ = 0;                                                                                                        \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= CAD_MAX_DEVICES) return CAD_ERR_LAUNCH;                 \
+        if (lds > 65536 && lds > cur[dev_]) {                                                                                \
+            if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                return CAD_ERR_LAUNCH;                                                                                       \
+            cur[dev_] = lds;                                                                                                 \
+        }                                                                                                                    \
+    } while (0)
+#else
+#define CX_BIG_LDS(kern) (void)0
+#endif
+    if (nsets == 1) {
+        CX_BIG_LDS((conv_xproj_bwd_kernel<1>));
+        CAD_LAUNCH((conv_xproj_bwd_kernel<1>), grid, block, lds, stream, ks);
+    } else {
+        CX_BIG_LDS((conv_xproj_bwd_kernel<2>));
+        CAD_LAUNCH((conv_xproj_bwd_kernel<2>), grid, block, lds, stream, ks);
+    }
+#undef CX_BIG_LDS
+    return cad_after_launch();
+}

@@ -75,10 +75,12 @@ static_assert(SC_CHUNK == SC_STATE_STEP, "backward chunk = one saved-state slot"
 // segment, pair), so halving the segment doubles ~40 % of the instructions per element (the forward built that way measured -15 %,
 // profiles/r03_occupancy_experiments.txt); (iii) the packed slab / MFMA flush / 16-byte LDS-DMA vectors are laid out for 8 items.
 static_assert(SC_S_BWD == 8, "the backward scan is written for 8 items per lane (see the comment above)");
-// -DSC_BWD_UNROLL_NP=8: A/B instantiation with the pair loop fully unrolled for d_state = 16 (compile-time pair index: lane
-// selections become immediates, the tile-buffer parity and the `more` / staging conditions fold)
+// SC_BWD_UNROLL_NP = 8: the production instantiation (bf16, vector path, d_state = 16) has its pair loop fully unrolled -- the pair
+// index is a compile-time constant, so lane selections become immediates and the tile-buffer parity and the `more` / staging
+// conditions fold: 3.93 -> 3.80 ms per two-set launch in a same-box A/B (profiles/r04_scan_bwd_floor_and_unroll.txt; 244 VGPRs, no
+// scratch).  Every other shape runs the generic instantiation (NPC = 0: run-time pair count).  -DSC_BWD_UNROLL_NP=0: round-3 kernel.
 #ifndef SC_BWD_UNROLL_NP
-#define SC_BWD_UNROLL_NP 0
+#define SC_BWD_UNROLL_NP 8
 #endif
 static_assert(SC_W == 4 || SC_W == 8, "staging needs >= 256 threads; the flush mapping is written for 256 / 512");
 
