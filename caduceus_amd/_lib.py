@@ -52,6 +52,11 @@ class Conv1dArgs(C.Structure):
                 ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
 
 
+class ProjTmArgs(C.Structure):
+    _fields_ = [("W", _p), ("X", _p), ("X2", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
+                ("ldo", _i64)]
+
+
 class ConvXprojBwdArgs(C.Structure):
     _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("du", _p), ("ddbc", _p), ("wxT", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
                 ("dwx_partials", _p), ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("M", _i),
@@ -148,6 +153,8 @@ SYMBOLS = {
     "cad_proj_wx_wgrad_supported": (_i, [_i, _i, _i64]),
     "cad_proj_wx_wgrad_partials": (_i, [_i64]),
     "cad_proj_wgrad_only_supported": (_i, [_i, _i, _i64]),
+    "cad_proj_xTw": (_i, [C.POINTER(ProjTmArgs), _p]),
+    "cad_proj_xTw_supported": (_i, [_i, _i, _i64]),
     "cad_quant_rows_fp8": (_i, [C.POINTER(QuantFp8Args), _p]),
     "cad_proj_wxT_fp8": (_i, [C.POINTER(ProjFp8Args), _p]),
     "cad_proj_fp8_supported": (_i, [_i]),

@@ -636,6 +636,117 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
     }
 }
 
+
+// ---- cad_proj_xTw:  out (T, M) TOKEN-major  =  sum over panels p of  X_p (K, T)^T . W (M, K)^T ----------------------------------------
+// out_proj of the tied BiMamba mixer: out = W_out (y_f + y_r) with y_f, y_r the two scans' channel-major outputs -- two panels that
+// share ONE weight, so the kernel walks K = d_inner per panel with the SAME resident W fragments (the library GEMM it replaces
+// multiplied the concatenation [y_f ; y_r] by a doubled weight [W_out, W_out] that had to be built per layer and step).
+// "W-stationary" as cad_proj_wxT: wave w owns output features 16 MB w .. and keeps their MB x K / 32 A-fragments in registers for the
+// whole launch; the workgroup walks blocks of 128 tokens, X travels by LDS-DMA in [64 rows][128 tokens] chunks through the ring of
+// cad_proj_wx's thin kernel (same swizzle, same counted waits).  MFMA roles: A = W fragment (rows = output features), B = X fragment
+// by transposing reads (columns = tokens), so a D lane holds FOUR CONSECUTIVE FEATURES of one token = 8 contiguous bytes of the
+// token-major output; fp32 accumulation over both panels and all of K, one rounding to bf16.
+template <int MB, int KS>
+__global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_args a) {
+    typedef GtCfg C;
+    CAD_DYN_SMEM(char, smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const int g = lane >> 4, jl = lane & 15;
+    const bf16_t* W = (const bf16_t*)a.W;
+    bf16_t* out = (bf16_t*)a.out;
+    const int64_t T = a.T;
+    const int M = a.M;
+    constexpr int NCH = KS / 2;                       // 64-row chunks per panel
+    const int NP = a.X2 ? 2 : 1;
+    const int per_blk = NP * NCH;                     // chunks per token block
+    const int64_t nblk = (T + C::NT - 1) / C::NT;
+    const int64_t b0 = blockIdx.x, bstep = gridDim.x;
+    if (b0 >= nblk) return;
+    const int64_t nmine = (nblk - b0 + bstep - 1) / bstep;
+    const int64_t total = nmine * per_blk;
+    const int m_wave = wave * 16 * MB;
+    // position of the next chunk to issue, carried as counters (no division on the issue path)
+    int ich = 0, ipan = 0, islot = 0;
+    int64_t iblk = b0;
+    auto issue_next = [&]() {
+        gt_issue_chunk((const bf16_t*)(ipan ? a.X2 : a.X), a.ldx, ich * C::KC, iblk * C::NT, T, smem + islot * C::XBUF, wave, lane);
+        islot = (islot + 1) & (C::RING - 1);
+        if (++ich == NCH) {
+            ich = 0;
+            if (++ipan == NP) {
+                ipan = 0;
+                iblk += bstep;
+            }
+        }
+    };
+    for (int64_t it = 0; it < C::RING - 1; ++it)
+        if (it < total) issue_next();
+    // A fragments of this wave's rows of W, resident for the whole launch (rows >= M read as zero)
+    u32x4 wf[MB][KS];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = m_wave + mb * 16 + jl;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < M) v = *(const u32x4*)(W + (int64_t)m * a.ldw + ks * 32 + g * 8);
+            wf[mb][ks] = v;
+        }
+    }
+    f32x4 d[C::NT / 16][MB];
+    int slot = 0;
+    int64_t blk = b0;
+    for (int64_t bi = 0; bi < nmine; ++bi, blk += bstep) {
+#pragma unroll
+        for (int q = 0; q < C::NT / 16; ++q)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) d[q][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pan = 0; pan < NP; ++pan) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int64_t it = (bi * NP + pan) * NCH + ch;
+#ifndef CAD_EMU
+                if (it + C::RING - 2 < total)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (output stores issued behind the DMA only make this wait stricter)
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                __syncthreads();  // every wave's share of the chunk is visible; the tile consumed LAST iteration is free again
+                if (it + C::RING - 1 < total) issue_next();
+                const char* xt = smem + slot * C::XBUF;
+                slot = (slot + 1) & (C::RING - 1);
+#pragma unroll
+                for (int q = 0; q < C::NT / 16; ++q) {
+#pragma unroll
+                    for (int ks = 0; ks < C::KC / 32; ++ks) {
+                        const int r0 = ks * 32 + g * 8 + (jl >> 2);
+                        const char* p0 = xt + r0 * C::XROW + ((q ^ gx_swz(r0)) * 32) + (jl & 3) * 8;
+                        const char* p1 = xt + (r0 + 4) * C::XROW + ((q ^ gx_swz(r0 + 4)) * 32) + (jl & 3) * 8;
+                        const u32x2 lo = cad_lds_read_tr16(p0), hi = cad_lds_read_tr16(p1);
+                        const u32x4 xf = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) d[q][mb] = cad_mfma_16x16x32_bf16(wf[mb][ch * 2 + ks], xf, d[q][mb]);
+                    }
+                }
+            }
+        }
+        // lane (token 16 q + jl, features m_wave + 16 mb + 4 g .. + 3): 8 bytes of the token's output row
+#pragma unroll
+        for (int q = 0; q < C::NT / 16; ++q) {
+            const int64_t t = blk * C::NT + q * 16 + jl;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = m_wave + mb * 16 + g * 4;
+                u32x2 pk;
+                pk[0] = cad_pack_bf16x2_safe(d[q][mb][0], d[q][mb][1]);
+                pk[1] = cad_pack_bf16x2_safe(d[q][mb][2], d[q][mb][3]);
+                if (t < T && m + 4 <= M) cad_store_stream<CAD_STREAM_PROJ>((u32x2*)(out + t * a.ldo + m), pk);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // more than 64 KB of dynamic LDS has to be requested per kernel: the largest size asked for so far is remembered per
@@ -799,4 +910,33 @@ extern "C" int cad_proj_wx_wgrad(const cad_proj_args* a, void* stream) {
     CAD_CHECK_ARG(((uintptr_t)a->W % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
     if (a->M == 16) return a->K == 256 ? launch_wx_wgrad<1, 4, true>(a, stream) : launch_wx_wgrad<1, 8, true>(a, stream);
     return a->K == 256 ? launch_wx_wgrad<2, 4, true>(a, stream) : launch_wx_wgrad<2, 8, true>(a, stream);
+}
+
+
+// ---- cad_proj_xTw ------------------------------------------------------------------------------------------------------------------
+extern "C" int cad_proj_xTw_supported(int M, int K, int64_t T) {
+    return (M == 128 || M == 256) && (K == 256 || K == 512) && T >= 8 && (T % 8) == 0;
+}
+
+template <int MB, int KS>
+static int launch_xTw(const cad_proj_tm_args* a, void* stream) {
+    const int64_t nblk = (a->T + GtCfg::NT - 1) / GtCfg::NT;
+    int64_t gx = 256;  // one workgroup per CU
+    if (gx > nblk) gx = nblk;
+    const size_t lds = (size_t)GtCfg::RING * GtCfg::XBUF;
+    dim3 grid((unsigned)gx), block(64 * GP_WAVES);
+    GP_BIG_LDS((proj_xTw_kernel<MB, KS>), lds);
+    CAD_LAUNCH((proj_xTw_kernel<MB, KS>), grid, block, lds, stream, *a);
+    return cad_after_launch();
+}
+
+extern "C" int cad_proj_xTw(const cad_proj_tm_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->W && a->X && a->out && a->T > 0 && a->M > 0 && a->K > 0);
+    if (!cad_proj_xTw_supported(a->M, a->K, a->T)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->M);
+    CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 4) == 0);
+    CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X | (uintptr_t)a->X2) % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
+    CadProfScope prof(8, stream);
+    if (a->M == 256) return a->K == 512 ? launch_xTw<2, 16>(a, stream) : launch_xTw<2, 8>(a, stream);
+    return a->K == 512 ? launch_xTw<1, 16>(a, stream) : launch_xTw<1, 8>(a, stream);
 }

@@ -140,6 +140,8 @@ _FUSED_SOFTPLUS = os.environ.get("CADUCEUS_AMD_FUSED_SOFTPLUS", "1") != "0"
 _FUSED_WGRAD = os.environ.get("CADUCEUS_AMD_FUSED_WGRAD", "1") != "0"
 # dW_x = d(dbc) . xc^T on the weight-gradient stage of the same kernel (W == NULL) instead of the GEMM library + a partial sum
 _OWN_DWX = os.environ.get("CADUCEUS_AMD_OWN_DWX", "1") != "0"
+# out_proj forward on the own token-major-output MFMA kernel (cad_proj_xTw); CADUCEUS_AMD_OWN_OUT_PROJ=0: hipBLASLt on [y_f ; y_r]
+_OWN_OUT_PROJ = os.environ.get("CADUCEUS_AMD_OWN_OUT_PROJ", "1") != "0"
 # conv1d backward + x_proj input gradient (du += W_x^T d(dbc)) + dW_x in ONE kernel (cad_conv_xproj_bwd_multi, csrc/conv1d.hip):
 # d(xc) never goes to memory, xc is recomputed from x instead of re-read.  CADUCEUS_AMD_FUSED_CONV_XPROJ=0 keeps the three-kernel path.
 _FUSED_CONV_XPROJ = os.environ.get("CADUCEUS_AMD_FUSED_CONV_XPROJ", "1") != "0"
@@ -296,7 +298,11 @@ class BiMambaMixerFn(torch.autograd.Function):
             states.append(state)
         _keep, seg_P = ops.scan_fwd_launch(lib, args, 2, stream, k, [st[2] for st in sets], dirs, split)
         y_f, y_r = outs
-        out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
+        if _OWN_OUT_PROJ and ops.proj_xTw_supported(ycat, Dm, E, T):
+            # W_out (y_f + y_r): both panels through one set of resident W_out fragments, token-major output (cad_proj_xTw)
+            out2d = ops.proj_xTw(w_out, y_f.view(E, T), y_r.view(E, T))
+        else:
+            out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
         wT = cache.get("wT") if cache else None
         keep = [x2d, xz, w_in, w_out, ycat]
         for i in range(2):

@@ -600,6 +600,24 @@ FP8 = torch.float8_e4m3fn
 FP8_MAX = 448.0
 
 
+def proj_xTw_supported(X: torch.Tensor, M: int, K: int, T: int) -> bool:
+    return X.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_xTw_supported(int(M), int(K), int(T)))
+
+
+def proj_xTw(W: torch.Tensor, X: torch.Tensor, X2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (T, M) token-major = X (K, T)^T @ W (M, K)^T [+ X2 (K, T)^T @ W^T], X / X2 channel-major bf16 (cad_proj_xTw): out_proj on the
+    sum of the two directions' scan outputs through ONE set of resident weight fragments, fp32 accumulation over both panels."""
+    M, K = W.shape
+    T = X.shape[1]
+    if out is None:
+        out = torch.empty((T, M), dtype=X.dtype, device=X.device)
+    stream = L.stream_and_check(W, X, X2, out)
+    assert W.stride(1) == 1 and X.stride(1) == 1 and out.stride(1) == 1 and (X2 is None or (X2.stride() == X.stride() and X2.shape == X.shape))
+    a = L.ProjTmArgs(L.ptr(W), L.ptr(X), L.ptr(X2), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0))
+    L.check(L.get_lib().cad_proj_xTw(C.byref(a), stream), "cad_proj_xTw")
+    return out
+
+
 def fp8_proj_supported(t: torch.Tensor, K: int) -> bool:
     return t.dtype in (torch.bfloat16, torch.float32) and bool(L.get_lib().cad_proj_fp8_supported(int(K)))
 

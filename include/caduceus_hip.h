@@ -354,6 +354,23 @@ int cad_proj_wx_wgrad_supported(int M, int K, int64_t T);
 int cad_proj_wgrad_only_supported(int M, int K, int64_t T);
 int cad_proj_wx_wgrad_partials(int64_t T);
 
+/* cad_proj_xTw:  out (T, M) TOKEN-major = X (K, T)^T . W (M, K)^T  [+ X2 (K, T)^T . W (M, K)^T],  X / X2 channel-major, all bf16 --
+ * the `out_proj` nn.Linear of mamba_inner_fn on the sum of the two directions' scan outputs (modeling_caduceus.py:128-138: with
+ * bidirectional_strategy "add" and tied weights, out_proj(y_f) + out_proj(y_r) = W_out (y_f + y_r)): both panels go through the same
+ * resident weight fragments, fp32 accumulation over both, one rounding.  X2 == NULL: a single panel.
+ * M in {128, 256} (= d_model), K in {256, 512} (= d_inner), T % 8 == 0 (cad_proj_xTw_supported); ldw / ldx multiples of 8, ldo of 4. */
+typedef struct {
+    const void* W;
+    const void* X;
+    const void* X2;
+    void* out;
+    int64_t T;
+    int M, K;
+    int64_t ldw, ldx, ldo;
+} cad_proj_tm_args;
+int cad_proj_xTw(const cad_proj_tm_args* a, void* stream);
+int cad_proj_xTw_supported(int M, int K, int64_t T);
+
 /* ---------------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) projections -- BASELINE configs[4] "fp8 MFMA projections": the same `in_proj` nn.Linear call of
  * mamba_ssm.Mamba.forward (modeling_caduceus.py:128,130) on v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation.

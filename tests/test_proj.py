@@ -194,3 +194,49 @@ def test_mixer_layer_own_wgrad_kernels_match_the_library_path(backend, monkeypat
         a, b = res[True][k], res[False][k]
         rel = float((a - b).norm() / b.norm().clamp_min(1e-20))
         assert rel < (2e-2 if ("x_proj" in k or "dt_proj.weight" in k) else 1e-2), (k, rel)
+
+
+@pytest.mark.parametrize("M,K,T,panels", [(256, 512, 384, 2), (256, 512, 200, 1), (128, 256, 136, 2), (256, 256, 128, 2), (128, 512, 1000, 2)])
+def test_proj_xTw_token_major_out_proj(backend, M, K, T, panels):
+    """cad_proj_xTw: out (T, M) token-major = (X1 + X2)^T W^T with fp32 accumulation over BOTH panels (out_proj of the tied BiMamba
+    mixer on y_f, y_r) -- against the fp32 product, and bit-for-bit against one rounding of it where the sum is exact."""
+    name, dev = backend
+    W, X1 = _bf(M, K, seed=31), _bf(K, T, seed=32)
+    X2 = _bf(K, T, seed=33) if panels == 2 else None
+    assert ops.proj_xTw_supported(X1.to(dev), M, K, T)
+    out = ops.proj_xTw(W.to(dev), X1.to(dev), None if X2 is None else X2.to(dev))
+    assert out.shape == (T, M) and out.dtype == torch.bfloat16
+    ref = X1.float().t() @ W.float().t()
+    if X2 is not None:
+        ref = ref + X2.float().t() @ W.float().t()
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max()) / 8)
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 8)
+    # position independence: permuting the tokens permutes the output rows bit for bit (RC-equivariance of the t-frame)
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(5))
+    out_p = ops.proj_xTw(W.to(dev), X1[:, perm].contiguous().to(dev), None if X2 is None else X2[:, perm].contiguous().to(dev))
+    assert torch.equal(out.cpu()[perm], out_p.cpu())
+
+
+def test_mixer_layer_own_out_proj_matches_the_library_path(backend, monkeypatch):
+    """One BiMamba mixer layer forward + backward with out_proj on cad_proj_xTw against the hipBLASLt / torch path on [y_f ; y_r]."""
+    from caduceus_amd import mixer
+    from caduceus_amd.mamba import Mamba
+    name, dev = backend
+    torch.manual_seed(3)
+    D, Lq = 128, 256
+    mf, mr = Mamba(D, device=dev), Mamba(D, device=dev)
+    mr.in_proj.weight = mf.in_proj.weight
+    mr.out_proj.weight = mf.out_proj.weight
+    hn0 = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    g = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    res = {}
+    for own in (True, False):
+        monkeypatch.setattr(mixer, "_OWN_OUT_PROJ", own)
+        for p in list(mf.parameters()) + list(mr.parameters()):
+            p.grad = None
+        hn = hn0.clone().requires_grad_(True)
+        out = mixer.bimamba_mixer(hn, mf, mr, 1)
+        out.backward(g)
+        res[own] = (out.detach().float().cpu(), hn.grad.float().cpu(), mf.out_proj.weight.grad.float().cpu())
+    for a, b in zip(res[True], res[False]):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * max(1.0, float(b.abs().max())))
