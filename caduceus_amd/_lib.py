@@ -57,12 +57,6 @@ class ProjTmArgs(C.Structure):
                 ("ldo", _i64)]
 
 
-class ConvXprojBwdArgs(C.Structure):
-    _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("du", _p), ("ddbc", _p), ("wxT", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
-                ("dwx_partials", _p), ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("M", _i),
-                ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i), ("ld_ddbc", _i64), ("ldw", _i64)]
-
-
 class Conv1dBwdArgs(C.Structure):
     _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("dout", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
                 ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i),
@@ -131,9 +125,6 @@ SYMBOLS = {
     "cad_conv1d_bwd": (_i, [C.POINTER(Conv1dBwdArgs), _p]),
     "cad_conv1d_fwd_multi": (_i, [C.POINTER(Conv1dArgs), _i, _p]),
     "cad_conv1d_bwd_multi": (_i, [C.POINTER(Conv1dBwdArgs), _i, _p]),
-    "cad_conv_xproj_bwd_multi": (_i, [C.POINTER(ConvXprojBwdArgs), _i, _p]),
-    "cad_conv_xproj_bwd_supported": (_i, [_i, _i, _i, _i64, _i64]),
-    "cad_conv_xproj_bwd_partials": (_i, [_i, _i64, _i64]),
     "cad_scan_fwd": (_i, [C.POINTER(ScanArgs), _p]),
     "cad_scan_chunk_len": (_i64, []),
     "cad_scan_state_floats": (_i64, [_i, _i64, _i64, _i]),

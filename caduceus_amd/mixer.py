@@ -74,27 +74,6 @@ def _conv_bwd2(x, params, douts, dx, split, dirs, bufs=None):
     return res
 
 
-def _conv_xproj_bwd2(x, params, dus, ddbcs, wxTs, dx, split, dirs, bufs):
-    """Fused conv1d backward + x_proj input / weight gradients of both parameter sets (cad_conv_xproj_bwd_multi):
-    d(xc) = du + W_x^T d(dbc) is formed on chip, dx = dx_f + dx_r is written once, dW_x comes from xc recomputed out of x.
-    Returns the (nsets, P, E, M) fp32 partial slots of dW_x^T (dW_x = slots.sum(1).transpose(1, 2))."""
-    E, SB, Lq = x.shape
-    n = len(params)
-    M = ddbcs[0].shape[0]
-    lib = L.get_lib()
-    slots = torch.empty((n, lib.cad_conv_xproj_bwd_partials(E, SB, Lq), E, M), dtype=torch.float32, device=x.device)
-    args = (L.ConvXprojBwdArgs * n)()
-    for i, (wf, bf) in enumerate(params):
-        dw, db = bufs[i]
-        ddbc = ddbcs[i].reshape(M, SB * Lq)
-        stream = L.stream_and_check(x, wf, bf, dus[i], ddbc, wxTs[i], dx, dw, db, slots)
-        args[i] = L.ConvXprojBwdArgs(L.ptr(x), L.ptr(wf), L.ptr(bf), L.ptr(dus[i]), L.ptr(ddbc), L.ptr(wxTs[i]), L.ptr(dx), L.ptr(dw),
-                                     L.ptr(db), C.c_void_p(slots[i].data_ptr()), SB, Lq, split, E, wf.shape[1], M, dirs[i][0],
-                                     dirs[i][1], L.dtype_code(x.dtype), ddbc.stride(0), wxTs[i].stride(0))
-    L.check(lib.cad_conv_xproj_bwd_multi(args, n, stream), "cad_conv_xproj_bwd_multi")
-    return slots
-
-
 def _kchunks(T: int) -> int:
     """Number of K-chunks for the weight-gradient GEMMs (reduction over all T tokens, tiny outputs).  hipBLASLt does not
     split K by itself for these shapes (0.6 ms at 0.65 TB/s); as a strided-batch GEMM over 64 chunks plus an fp32 sum of
@@ -142,9 +121,6 @@ _FUSED_WGRAD = os.environ.get("CADUCEUS_AMD_FUSED_WGRAD", "1") != "0"
 _OWN_DWX = os.environ.get("CADUCEUS_AMD_OWN_DWX", "1") != "0"
 # out_proj forward on the own token-major-output MFMA kernel (cad_proj_xTw); CADUCEUS_AMD_OWN_OUT_PROJ=0: hipBLASLt on [y_f ; y_r]
 _OWN_OUT_PROJ = os.environ.get("CADUCEUS_AMD_OWN_OUT_PROJ", "1") != "0"
-# conv1d backward + x_proj input gradient (du += W_x^T d(dbc)) + dW_x in ONE kernel (cad_conv_xproj_bwd_multi, csrc/conv1d.hip):
-# d(xc) never goes to memory, xc is recomputed from x instead of re-read.  CADUCEUS_AMD_FUSED_CONV_XPROJ=0 keeps the three-kernel path.
-_FUSED_CONV_XPROJ = os.environ.get("CADUCEUS_AMD_FUSED_CONV_XPROJ", "1") != "0"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
@@ -349,9 +325,6 @@ class BiMambaMixerFn(torch.autograd.Function):
         n_fix = lib.cad_scan_gate_fix_entries(E, SB, Lq)
         fix_list = [torch.empty((n_fix,), dtype=torch.int64, device=x2d.device) for _ in range(2)]
         wg_dt = wg_x = None  # fp32 partial slots of the own weight-gradient kernels, both sets
-        Mx = sets[0][3].shape[0]  # R + 2N
-        conv_K = sets[0][6].shape[1]
-        fuse_cx = (_FUSED_CONV_XPROJ and act == torch.bfloat16 and bool(lib.cad_conv_xproj_bwd_supported(E, conv_K, Mx, SB, Lq)))
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
             N = A.shape[1]
@@ -402,11 +375,6 @@ class BiMambaMixerFn(torch.autograd.Function):
                 else:
                     torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
                 dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
-            if fuse_cx:
-                # x_proj's input gradient, dW_x and the conv backward run as ONE kernel after the loop (cad_conv_xproj_bwd_multi)
-                dxcs.append((du, ddbc, wT["x"][i] if wT else w_x.t().contiguous()))
-                part.append((None, dW_dt, dbias, dA * A, dD))
-                continue
             if _OWN_DWX and ops.proj_wgrad_only_supported(xc, R + 2 * N, E, T):
                 if wg_x is None:
                     wg_x = ops.wgrad_partials(T, E, R + 2 * N, xc.device, nsets=2)
@@ -422,21 +390,13 @@ class BiMambaMixerFn(torch.autograd.Function):
                 du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))
             dxcs.append(du)
             part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
-        cbufs = [(zbuf[5 * i + 3], zbuf[5 * i + 4] if sets[i][7] is not None else None) for i in range(2)]
-        sum_x = None
-        if fuse_cx:
-            slots = _conv_xproj_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], [d[0] for d in dxcs], [d[1] for d in dxcs],
-                                     [d[2] for d in dxcs], dxz[:E], split, dirs, cbufs)
-            conv_g = cbufs
-            sum_x = slots.sum(dim=1).transpose(1, 2).contiguous()  # (2, P, E, M) -> (2, M, E), fixed order
-        else:
-            conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs, bufs=cbufs)
+        conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs,
+                            bufs=[(zbuf[5 * i + 3], zbuf[5 * i + 4] if sets[i][7] is not None else None) for i in range(2)])
         # one fold per weight for BOTH sets' partial slots (fixed order): (2, P, K, M) -> (2, K, M) / (2, M, K)
         sum_dt = None if wg_dt is None else wg_dt.sum(dim=1)
         # (the slots hold (K, M); summed as they lie -- a reduction over a permuted view runs at a quarter of the rate -- and the
         # small (2, K, M) result is transposed)
-        if wg_x is not None:
-            sum_x = wg_x.sum(dim=1).transpose(1, 2).contiguous()
+        sum_x = None if wg_x is None else wg_x.sum(dim=1).transpose(1, 2).contiguous()
         for i in range(2):
             meta = pmeta[i]
             (dwc, dbc_conv), (dW_x, dW_dt, dbias, dA_log, dD) = conv_g[i], part[i]

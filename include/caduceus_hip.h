@@ -164,36 +164,6 @@ int cad_conv1d_bwd(const cad_conv1d_bwd_args* a, void* stream);
 /* nsets (1 or 2) parameter sets with the same x, dx and accumulate flag: dx = (accumulate ? dx : 0) + sum over the sets. */
 int cad_conv1d_bwd_multi(const cad_conv1d_bwd_args* sets, int nsets, void* stream);
 
-/* Fused backward of the conv1d and of the x_proj nn.Linear that feeds on its output (both inside mamba_inner_fn's backward, reached
- * from modeling_caduceus.py:128,130):
- *   d(xc) = du + W_x^T . d(dbc)   (the input gradient of x_proj, added to the scan's du; never written to memory),
- *   dx, dw, dbias                 = cad_conv1d_bwd of d(xc)  (dx WRITTEN = the sum over the sets; dw / dbias ACCUMULATED, caller zeroes),
- *   dW_x (E, M)                   = xc . d(dbc)^T with xc = silu(conv(x)) RECOMPUTED from x (bit-identical to cad_conv1d_fwd's output).
- * bf16 only.  x, du, dx: (E, SB, L);  ddbc: (M, SB * L) rows ld_ddbc elements apart (M = dt_rank + 2 d_state, a multiple of 8, <= 64);
- * wxT: (E, M) bf16 = the TRANSPOSE of x_proj.weight, rows ldw elements apart;  dwx_partials: cad_conv_xproj_bwd_partials(E, SB, L)
- * slots of (E, M) fp32, WRITTEN (no zeroing) -- dW_x^T = the sum over the slots (fixed order: deterministic).
- * Requires cad_conv_xproj_bwd_supported (E % 32 == 0, L % 8 == 0, 16-byte aligned tensors). */
-typedef struct {
-    const void* x;
-    const float* w;
-    const float* bias;
-    const void* du;
-    const void* ddbc;
-    const void* wxT;
-    void* dx;
-    float* dw;
-    float* dbias;
-    float* dwx_partials;
-    int64_t SB, L, split;
-    int E, K, M;
-    int rev_lo, rev_hi;
-    int dtype;
-    int64_t ld_ddbc, ldw;
-} cad_conv_xproj_bwd_args;
-int cad_conv_xproj_bwd_multi(const cad_conv_xproj_bwd_args* sets, int nsets, void* stream);
-int cad_conv_xproj_bwd_supported(int E, int K, int M, int64_t SB, int64_t L);
-int cad_conv_xproj_bwd_partials(int E, int64_t SB, int64_t L);
-
 /* ---------------------------------------------------------------------------------------------------------
  * Selective SSM scan, one direction per row.   Replaces selective_scan_cuda.fwd / .bwd reached through
  * mamba_ssm.Mamba.forward -> mamba_inner_fn (modeling_caduceus.py:128,130):

@@ -567,56 +567,3 @@ def test_kernel_timer_counts_only_the_enabled_kinds(backend):
         CL.prof_enable(False)
         CL.prof_reset()
 
-
-@pytest.mark.parametrize("case", [(32, 2, 1000, 48, 4, 1), (64, 3, 2048, 48, 4, 2), (32, 1, 496, 24, 3, 0), (64, 2, 8, 48, 4, 1), (32, 2, 5000, 40, 2, 1)])
-def test_fused_conv_xproj_backward_matches_the_three_kernels(backend, case):
-    """cad_conv_xproj_bwd_multi = cad_proj_wx (du += W_x^T d(dbc)) -> cad_conv1d_bwd_multi, + dW_x = d(dbc) . xc^T with xc RECOMPUTED
-    from x.  dx must be bit-identical (same product instruction, same rounding points, same tap order); the reductions over positions
-    (dw, dbias, dW_x) are fp32 sums in a different grouping.  Tiles of 496 useful positions: the cases cover a ragged last tile, a
-    row that is one tile exactly, rows shorter than a tile and three rows with the direction split inside the batch."""
-    from caduceus_amd import mixer
-    name, dev = backend
-    E, SB, L, M, K, split = case
-    g = torch.Generator().manual_seed(11)
-    bf = torch.bfloat16
-    x = torch.randn(E, SB, L, generator=g).to(dev).to(bf)
-    params = [(torch.randn(E, K, generator=g).to(dev), torch.randn(E, generator=g).to(dev)) for _ in range(2)]
-    dus = [torch.randn(E, SB, L, generator=g).to(dev).to(bf) for _ in range(2)]
-    ddbcs = [torch.randn(M, SB, L, generator=g).to(dev).to(bf) for _ in range(2)]
-    wxs = [(0.2 * torch.randn(M, E, generator=g)).to(dev).to(bf) for _ in range(2)]
-    wxTs = [w.t().contiguous() for w in wxs]
-    dirs = ((0, 1), (1, 0))
-    assert ops.L.get_lib().cad_conv_xproj_bwd_supported(E, K, M, SB, L)
-    # --- the three-kernel path ---
-    T = SB * L
-    dx_ref = torch.empty_like(x)
-    xcs = mixer._conv_fwd2(x, params, split, dirs)
-    dxc = []
-    for i in range(2):
-        if ops.proj_wx_supported(dus[i], M, T):
-            d = ops.proj_wx(wxTs[i], ddbcs[i].view(M, T), acc=dus[i].view(E, T)).view(E, SB, L)
-        else:  # (T % 8 != 0 cannot happen here: L % 8 == 0)
-            raise AssertionError("thin-K projection kernel refused the shape")
-        dxc.append(d)
-    ref = mixer._conv_bwd2(x, params, dxc, dx_ref, split, dirs)
-    dwx_ref = [ddbcs[i].view(M, T).float() @ xcs[i].view(E, T).float().t() for i in range(2)]
-    # --- the fused kernel ---
-    dx = torch.empty_like(x)
-    bufs = [(torch.zeros_like(params[i][0]), torch.zeros_like(params[i][1])) for i in range(2)]
-    slots = mixer._conv_xproj_bwd2(x, params, dus, ddbcs, wxTs, dx, split, dirs, bufs)
-    # dx: the same operations in the same order -- on the emulator bit for bit; on the device the compiler schedules / contracts the two
-    # kernels' identical source expressions independently, and one element in ~4e5 lands on the other side of a bf16 rounding boundary
-    # (measured: 1 of 393216, 1 ulp): at most 1e-5 of the elements may differ, by one bf16 ulp
-    if name == "emu":
-        assert torch.equal(dx, dx_ref)
-    else:
-        bad = dx != dx_ref
-        assert int(bad.sum()) <= max(1, int(1e-5 * dx.numel())), int(bad.sum())
-        d = (dx.float() - dx_ref.float()).abs()
-        assert bool((d <= 2.0 ** -7 * dx_ref.float().abs() + 1e-30)[bad].all())
-    assert not ops.L.get_lib().cad_conv_xproj_bwd_supported(E, K, 64, SB, L)  # M = 64 (d_model 512): two tiles do not fit the LDS
-    dwx = slots.sum(dim=1).transpose(1, 2)
-    for i in range(2):
-        torch.testing.assert_close(bufs[i][0], ref[i][0], rtol=1e-4, atol=1e-4 * max(1.0, float(ref[i][0].abs().max())))
-        torch.testing.assert_close(bufs[i][1], ref[i][1], rtol=1e-4, atol=1e-4 * max(1.0, float(ref[i][1].abs().max())))
-        torch.testing.assert_close(dwx[i], dwx_ref[i], rtol=1e-4, atol=1e-4 * max(1.0, float(dwx_ref[i].abs().max())))
