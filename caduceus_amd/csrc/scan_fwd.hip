@@ -31,9 +31,14 @@ struct ScanFwdSets {
 #define PRE_SLOT (SC_W * 64 * 16)          // bytes per 16-byte plane (all waves)
 #define PRE_BYTES (8 * PRE_SLOT)           // u0 u1 d0 d1 | z0 z1 (even chunks) | z0 z1 (odd chunks)
 
+// SC_FWD_UNROLL_NP = 8: the production instantiation (bf16, vector path, d_state = 16) has its pair loop fully unrolled, as the backward
+// (compile-time pair index: ring slot, barrier parity and staging cursor fold).  -DSC_FWD_UNROLL_NP=0: the run-time loop everywhere.
+#ifndef SC_FWD_UNROLL_NP
+#define SC_FWD_UNROLL_NP 8
+#endif
 // MO = map-only instantiation (cad_scan_args.map_only, pass 1 of an L-split scan): recurrence and wave scan only -- hT and
 // sum_dt are the outputs; no C tile reads, no output phase, no gate, no stores of `out` / chunk states.
-template <typename T, bool VEC, bool MO>
+template <typename T, bool VEC, bool MO, int NPC = 0>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [SC_RING_FWD slots][B,C][SC_TILE]
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
@@ -50,7 +55,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const int e = act ? e_raw : a.E - 1;
     const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
     const int64_t L = a.L, SB = a.SB;
-    const int N = a.N, NP = (N + 1) >> 1;
+    const int N = NPC ? 2 * NPC : a.N, NP = NPC ? NPC : (a.N + 1) >> 1;  // NPC: compile-time pair count (the launcher checks N)
+    static_assert(NPC == 0 || (NPC % RING == 0 && NPC > AHEAD), "unrolled pair loop: the ring position restarts with every chunk");
     const int64_t row_off = ((int64_t)e * SB + sb) * L;
     const T* u_row = (const T*)a.u + row_off;
     const T* d_row = (const T*)a.delta + row_off;
@@ -194,8 +200,14 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             st_base[lane * 2 + 1] = carry[1];
         }
         SC_TIME(1);  // chunk prologue: loads, unpack, softplus
+        // (unrolled instantiation: tix = NPC * c + np with NPC a multiple of the ring size, so the slot, the barrier parity and the
+        // staging cursor -- which runs AHEAD pairs in front, still inside this chunk at np = 0 -- are functions of np alone)
+        if constexpr (NPC != 0) s_np = AHEAD;
+#if SC_FWD_UNROLL_NP
+#pragma unroll
+#endif
         for (int np = 0; np < NP; ++np, ++tix) {
-            const int buf = tix & (RING - 1);
+            const int buf = NPC ? (np & (RING - 1)) : (tix & (RING - 1));
             // prefetch the tile AHEAD pairs from now (this chunk's or the next one's)
             const bool more = tix + AHEAD < ntiles;
             if (more) SC_FWD_STAGE();
@@ -251,11 +263,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             }
             SC_TIME(4);  // output phase (C tile reads)
             if (more) {
-                sc_stage_store<T, SC_S, VEC>(st, smem + ((tix + AHEAD) & (RING - 1)) * 2 * TILE, rev, dma_now);
+                sc_stage_store<T, SC_S, VEC>(st, smem + ((NPC ? np + AHEAD : tix + AHEAD) & (RING - 1)) * 2 * TILE, rev, dma_now);
                 SC_FWD_ADVANCE();
             }
             SC_TIME(5);  // staging store
-            if (((tix + 1) & (AHEAD - 1)) == 0 && !(SC_WHATIF & 2)) __syncthreads();
+            if ((((NPC ? np : tix) + 1) & (AHEAD - 1)) == 0 && !(SC_WHATIF & 2)) __syncthreads();
             SC_TIME(6);  // barrier
         }
         if constexpr (MO) continue;  // no output of a map-only pass
@@ -328,7 +340,10 @@ extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* st
                          ((SC_FWD_DMA && vec && a->dtype == CAD_BF16 && SC_S == 16) ? PRE_BYTES : 0);
 #define SC_FWD_LAUNCH(T, V)                                                                  \
     do {                                                                                     \
-        if (a->map_only) {                                                                   \
+        if (SC_FWD_UNROLL_NP && !a->map_only && V && sizeof(T) == 2 && a->N == 2 * SC_FWD_UNROLL_NP) { \
+            SC_BIG_LDS((scan_fwd_kernel<T, V, false, SC_FWD_UNROLL_NP>), shmem);             \
+            CAD_LAUNCH((scan_fwd_kernel<T, V, false, SC_FWD_UNROLL_NP>), grid, block, shmem, stream, ks); \
+        } else if (a->map_only) {                                                            \
             SC_BIG_LDS((scan_fwd_kernel<T, V, true>), shmem);                                \
             CAD_LAUNCH((scan_fwd_kernel<T, V, true>), grid, block, shmem, stream, ks);       \
         } else {                                                                             \
