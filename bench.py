@@ -357,7 +357,7 @@ def main():
         # ... and only when the profile was taken on THIS build of the kernels (cad_version() carries a hash of the sources)
         traffic, traffic_note = None, "no counter profile for this launch shape"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_scan_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_scan_pmc.json")))
             sh = pmc["shape"]
             if dom and (sh["E"], sh["L"], sh["N"], sh["dtype"]) == (E, args.seqlen, N, args.dtype) and \
                     sh["rows"] == (2 if args.model == "ps" else 1) * args.batch:
@@ -365,9 +365,9 @@ def main():
                 if why:
                     traffic = pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"]
                     traffic_note = ("HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
-                                    "profiles/r03_scan_pmc.json taken on " + why)
+                                    "profiles/r04_scan_pmc.json taken on " + why)
                 else:
-                    traffic_note = (f"profiles/r03_scan_pmc.json was taken on another build ({pmc.get('lib_version')}); this "
+                    traffic_note = (f"profiles/r04_scan_pmc.json was taken on another build ({pmc.get('lib_version')}); this "
                                     f"library is {_lib.version()}: not quoted")
         except (OSError, KeyError, ValueError):
             traffic = None

@@ -646,6 +646,16 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
 // cad_proj_wx's thin kernel (same swizzle, same counted waits).  MFMA roles: A = W fragment (rows = output features), B = X fragment
 // by transposing reads (columns = tokens), so a D lane holds FOUR CONSECUTIVE FEATURES of one token = 8 contiguous bytes of the
 // token-major output; fp32 accumulation over both panels and all of K, one rounding to bf16.
+#ifndef GP_XTW_PLAIN_STORES
+#define GP_XTW_PLAIN_STORES 1   // ordinary stores: the 8-byte pieces of a token row meet in L2 (streaming stores of partial lines: 0.277 vs 0.212 ms)
+#endif
+#ifndef GP_XTW_RING
+#define GP_XTW_RING 4           // LDS tiles of the X ring: RING - 1 chunks (16 KB each) in flight per CU (8 slots measured SLOWER:
+                               // 0.222 vs 0.206 ms, profiles/r04_out_proj.txt)
+#endif
+#ifndef GP_XTW_KS_OUTER
+#define GP_XTW_KS_OUTER 1
+#endif
 template <int MB, int KS>
 __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_args a) {
     typedef GtCfg C;
@@ -658,6 +668,9 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
     const int64_t T = a.T;
     const int M = a.M;
     constexpr int NCH = KS / 2;                       // 64-row chunks per panel
+    constexpr int XR = GP_XTW_RING;                   // ring slots
+    constexpr int INFL = (XR - 2) * C::DPW;           // DMA instructions of the later chunks that may stay in flight at a wait
+    static_assert((XR & (XR - 1)) == 0 && XR >= 4, "ring slots are advanced with a mask");
     const int NP = a.X2 ? 2 : 1;
     const int per_blk = NP * NCH;                     // chunks per token block
     const int64_t nblk = (T + C::NT - 1) / C::NT;
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
     int64_t iblk = b0;
     auto issue_next = [&]() {
         gt_issue_chunk((const bf16_t*)(ipan ? a.X2 : a.X), a.ldx, ich * C::KC, iblk * C::NT, T, smem + islot * C::XBUF, wave, lane);
-        islot = (islot + 1) & (C::RING - 1);
+        islot = (islot + 1) & (XR - 1);
         if (++ich == NCH) {
             ich = 0;
             if (++ipan == NP) {
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
             }
         }
     };
-    for (int64_t it = 0; it < C::RING - 1; ++it)
+    for (int64_t it = 0; it < XR - 1; ++it)
         if (it < total) issue_next();
     // A fragments of this wave's rows of W, resident for the whole launch (rows >= M read as zero)
     u32x4 wf[MB][KS];
@@ -697,6 +710,9 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
     f32x4 d[C::NT / 16][MB];
     int slot = 0;
     int64_t blk = b0;
+    constexpr int NST = (C::NT / 16) * MB;           // output stores per wave and block
+    static_assert(INFL + NST <= 63, "vmcnt is a 6-bit counter");
+    int since_store = XR;                             // iterations since the last store burst (wave-uniform)
     for (int64_t bi = 0; bi < nmine; ++bi, blk += bstep) {
 #pragma unroll
         for (int q = 0; q < C::NT / 16; ++q)
@@ -706,20 +722,29 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int64_t it = (bi * NP + pan) * NCH + ch;
+                // chunk `it` has landed when at most the vector-memory operations issued AFTER its DMA are outstanding (vmcnt retires in
+                // issue order on gfx9-class hardware, loads, LDS-DMA and stores alike): the two later chunks (4 instructions) and -- for the
+                // three waits that follow a block's output stores -- those NST stores.  A plain vmcnt(4) there drained the stores AND the
+                // freshly issued prefetch once per block (200 instead of ~140 us per launch, profiles/r04_out_proj.txt).
 #ifndef CAD_EMU
-                if (it + C::RING - 2 < total)
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (output stores issued behind the DMA only make this wait stricter)
-                else
+                if (it + XR - 2 >= total || since_store < 0)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (since_store < XR - 1)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL + NST) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
 #endif
+                ++since_store;
                 __syncthreads();  // every wave's share of the chunk is visible; the tile consumed LAST iteration is free again
-                if (it + C::RING - 1 < total) issue_next();
+                if (it + XR - 1 < total) issue_next();
                 const char* xt = smem + slot * C::XBUF;
-                slot = (slot + 1) & (C::RING - 1);
+                slot = (slot + 1) & (XR - 1);
+                // (k step outer, token sub-block inner: consecutive MFMAs go to sixteen different accumulator tiles)
 #pragma unroll
-                for (int q = 0; q < C::NT / 16; ++q) {
+                for (int o1 = 0; o1 < (GP_XTW_KS_OUTER ? C::KC / 32 : C::NT / 16); ++o1) {
 #pragma unroll
-                    for (int ks = 0; ks < C::KC / 32; ++ks) {
+                    for (int o2 = 0; o2 < (GP_XTW_KS_OUTER ? C::NT / 16 : C::KC / 32); ++o2) {
+                        const int ks = GP_XTW_KS_OUTER ? o1 : o2, q = GP_XTW_KS_OUTER ? o2 : o1;
                         const int r0 = ks * 32 + g * 8 + (jl >> 2);
                         const char* p0 = xt + r0 * C::XROW + ((q ^ gx_swz(r0)) * 32) + (jl & 3) * 8;
                         const char* p1 = xt + (r0 + 4) * C::XROW + ((q ^ gx_swz(r0 + 4)) * 32) + (jl & 3) * 8;
@@ -741,9 +766,21 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
                 u32x2 pk;
                 pk[0] = cad_pack_bf16x2_safe(d[q][mb][0], d[q][mb][1]);
                 pk[1] = cad_pack_bf16x2_safe(d[q][mb][2], d[q][mb][3]);
-                if (t < T && m + 4 <= M) cad_store_stream<CAD_STREAM_PROJ>((u32x2*)(out + t * a.ldo + m), pk);
+                // (every lane issues the store: the counted waits above rely on exactly NST store instructions per block; lanes of a tail
+                // block / beyond M are masked off by the exec mask, the instruction still counts)
+                if (t < T && m + 4 <= M) {
+#if GP_XTW_PLAIN_STORES
+                    *(u32x2*)(out + t * a.ldo + m) = pk;
+#else
+                    cad_store_stream<CAD_STREAM_PROJ>((u32x2*)(out + t * a.ldo + m), pk);
+#endif
+                }
             }
         }
+        // (a block with masked-off store instructions -- the tail block, or a wave beyond M -- issued an unknown number of them: the
+        // next three waits drain everything instead)
+        // ... and so does a configuration whose blocks are shorter than the ring is deep (two store bursts inside one wait's window)
+        since_store = (blk * C::NT + C::NT <= T && m_wave + 16 * MB <= M && per_blk >= XR - 1) ? 0 : -XR;
     }
 }
 
@@ -923,7 +960,7 @@ static int launch_xTw(const cad_proj_tm_args* a, void* stream) {
     const int64_t nblk = (a->T + GtCfg::NT - 1) / GtCfg::NT;
     int64_t gx = 256;  // one workgroup per CU
     if (gx > nblk) gx = nblk;
-    const size_t lds = (size_t)GtCfg::RING * GtCfg::XBUF;
+    const size_t lds = (size_t)GP_XTW_RING * GtCfg::XBUF;
     dim3 grid((unsigned)gx), block(64 * GP_WAVES);
     GP_BIG_LDS((proj_xTw_kernel<MB, KS>), lds);
     CAD_LAUNCH((proj_xTw_kernel<MB, KS>), grid, block, lds, stream, *a);

@@ -146,7 +146,7 @@ def test_chunked_weight_gradient_gemms_match_plain_mm():
 
 
 def test_bench_quotes_a_counter_profile_only_for_the_profiled_scan_sources():
-    """bench.pmc_quotable: roofline.traffic comes from profiles/r03_scan_pmc.json only when that profile was taken on the loaded build, or
+    """bench.pmc_quotable: roofline.traffic comes from profiles/r04_scan_pmc.json only when that profile was taken on the loaded build, or
     on a build with the same scan sources while the loaded library is the build of this tree."""
     import importlib.util
     import os
@@ -163,8 +163,8 @@ def test_bench_quotes_a_counter_profile_only_for_the_profiled_scan_sources():
     assert bench.pmc_quotable(pmc, "caduceus_amd 0.1.0 (hip gfx950) src 111111111111") is None  # a stale library
     assert bench.pmc_quotable({"lib_version": pmc["lib_version"]}, cur) is None                   # an unstamped profile
     # the committed profile is quotable for the committed sources
-    committed = json.load(open(os.path.join(ROOT, "profiles", "r03_scan_pmc.json")))
-    assert bench.pmc_quotable(committed, cur), "profiles/r03_scan_pmc.json does not belong to the scan sources in the tree"
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r04_scan_pmc.json")))
+    assert bench.pmc_quotable(committed, cur), "profiles/r04_scan_pmc.json does not belong to the scan sources in the tree"
 
 
 # ---- the reference's import name (north_star: "train.py and the HF AutoModel path load it unchanged") ---------------------

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end evidence on ONE box: the GPU parity suite, smoke(), counter + trace profiles of the scans (-> profiles/r03_scan_pmc.json,
+# Round-end evidence on ONE box: the GPU parity suite, smoke(), counter + trace profiles of the scans (-> profiles/r04_scan_pmc.json,
 # stamped with cad_version()), the whole-step kernel trace, and the default bench line.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -24,5 +24,5 @@ if f:
     open("gpurun_out/step_trace_final.txt", "w").write("\n".join(out) + "\n")
     print("\n".join(out[:14]))
 PY
-cp gpurun_out/scan_pmc.json profiles/r03_scan_pmc.json  # (on the box: the bench line below quotes the counters taken on THIS build)
+cp gpurun_out/scan_pmc.json profiles/r04_scan_pmc.json  # (on the box: the bench line below quotes the counters taken on THIS build)
 timeout 400 python bench.py > gpurun_out/bench_final.log 2>gpurun_out/bench_final.err; tail -1 gpurun_out/bench_final.log | cut -c1-400
