@@ -38,7 +38,7 @@ class EmbedBwdArgs(C.Structure):
 class AddNormArgs(C.Structure):
     _fields_ = [("x", _p), ("residual_in", _p), ("weight", _p), ("bias", _p), ("y", _p), ("residual_out", _p),
                 ("rstd", _p), ("mean", _p), ("rows_per_strand", _i64), ("n_strands", _i), ("D", _i), ("eps", _f),
-                ("is_rms", _i), ("swap_flip", _i), ("x_dtype", _i), ("y_dtype", _i)]
+                ("is_rms", _i), ("swap_flip", _i), ("x_dtype", _i), ("y_dtype", _i), ("y_fp8", _p), ("y_scale", _p)]
 
 
 class AddNormBwdArgs(C.Structure):

@@ -4,6 +4,7 @@
 // One wave64 per token row; lane handles channels c = lane + 64*k.  HBM-bound elementwise kernel: every input
 // byte is read once and every output byte written once; statistics stay in registers (wave xor-reduction).
 #include "cad_common.h"
+#include "cad_fp8.h"
 #include "cad_stream.h"
 
 namespace {
@@ -16,6 +17,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+// the value a bf16 / fp32 store of `o` leaves in memory (the e4m3 copy is taken from the ROUNDED normed activation, so that it equals
+// cad_quant_rows_fp8 of the stored tensor bit for bit)
+template <typename TY>
+__device__ __forceinline__ float stored_value(float o) { return to_f32(from_f32<TY>(o)); }
 
 template <typename TX, typename TY>
 __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_kernel(cad_add_norm_args a) {
@@ -185,7 +195,7 @@ __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float* o) {
 
 // KMAX = 256-channel steps per lane: 1 for D <= 256 (a third of the registers of the general instantiation, twice the waves per
 // SIMD), 2 for D <= 512 (configs[4])
-template <typename TX, typename TY, int KMAX>
+template <typename TX, typename TY, int KMAX, bool FP8 = false>
 __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add_norm_args a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -248,6 +258,8 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add
             a.rstd[row] = rstd;
             if (a.mean) a.mean[row] = mean;
         }
+        float ov[KMAX][4];   // the normed row as it is stored (only read again for the e4m3 copy)
+        float amax = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int c = (lane + 64 * k) * 4;
@@ -265,7 +277,30 @@ __global__ __launch_bounds__(64 * AN_WAVES) void add_norm_fwd_vec_kernel(cad_add
                 }
                 cad_cvt_store_stream<CAD_STREAM_NORM, TY, 4>(y + orow * D + oc, o);
                 if (a.residual_out) cad_cvt_store_stream<CAD_STREAM_NORM, float, 4>(a.residual_out + orow * D + oc, ro);
+                if (FP8) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ov[k][q] = stored_value<TY>(o[q]);
+                        amax = fmaxf(amax, fabsf(ov[k][q]));
+                    }
+                }
             }
+        }
+        if (FP8) {
+            // BASELINE configs[4] (fp8 projections): the e4m3 operand of the in_proj is written HERE, by the kernel that produces the
+            // normed activations, with one scale per token (= output row) -- no separate quantisation pass over the tensor
+            amax = wave_max(amax);
+            const float scale = cad_fp8_row_scale(amax), inv = 1.0f / scale;
+            uint8_t* qrow = (uint8_t*)a.y_fp8 + orow * D;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int c = (lane + 64 * k) * 4;
+                if (c < D) {
+                    const int oc = a.swap_flip ? (D - 4 - c) : c;
+                    *(uint32_t*)(qrow + oc) = cad_pack_fp8x4(ov[k][0] * inv, ov[k][1] * inv, ov[k][2] * inv, ov[k][3] * inv);
+                }
+            }
+            if (lane == 0) a.y_scale[orow] = scale;
         }
     }
 }
@@ -383,9 +418,17 @@ extern "C" int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream) {
     dim3 grid((unsigned)nb), block(64 * AN_WAVES);
     const bool vec = (a->D % 4) == 0 && (((uintptr_t)a->x | (uintptr_t)a->residual_in | (uintptr_t)a->weight |
                                           (uintptr_t)a->bias | (uintptr_t)a->y | (uintptr_t)a->residual_out) % 16) == 0;
+    if (a->y_fp8) {  // the e4m3 copy is an epilogue of the vector kernels (every production shape)
+        CAD_CHECK_ARG(a->y_scale != nullptr);
+        if (!vec || a->D > 512 || ((uintptr_t)a->y_fp8 % 4) != 0) return CAD_ERR_UNSUPPORTED;
+    }
 #define AN_FWD(TX, TY)                                                                  \
     do {                                                                                \
-        if (vec && a->D <= 256)                                                         \
+        if (vec && a->y_fp8 && a->D <= 256)                                             \
+            CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, 1, true>), grid, block, 0, stream, *a);  \
+        else if (vec && a->y_fp8)                                                       \
+            CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, 2, true>), grid, block, 0, stream, *a);  \
+        else if (vec && a->D <= 256)                                                    \
             CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, 1>), grid, block, 0, stream, *a);  \
         else if (vec && a->D <= 512)                                                    \
             CAD_LAUNCH((add_norm_fwd_vec_kernel<TX, TY, 2>), grid, block, 0, stream, *a);  \

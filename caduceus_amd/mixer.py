@@ -129,6 +129,10 @@ _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
 def set_fp8_in_proj(on: bool) -> None:
     global _FP8_IN_PROJ
     _FP8_IN_PROJ = bool(on)
+    ops.FP8_ACTIVATIONS = _FP8_IN_PROJ
+
+
+ops.FP8_ACTIVATIONS = _FP8_IN_PROJ
 
 
 def prepare_step_cache(pairs, act: torch.dtype) -> None:
@@ -206,7 +210,7 @@ class BiMambaMixerFn(torch.autograd.Function):
     conv_w (E,1,K), conv_b (E), W_x (R+2N, E), W_dt (E, R), dt_bias (E), A_log (E, N), D (E)."""
 
     @staticmethod
-    def forward(ctx, x2d, SB, Lq, split, cache, W_in, W_out, *ps):
+    def forward(ctx, x2d, SB, Lq, split, cache, fp8_act, W_in, W_out, *ps):
         lib = L.get_lib()
         act = x2d.dtype
         T, Dm = x2d.shape
@@ -218,7 +222,8 @@ class BiMambaMixerFn(torch.autograd.Function):
         if _FP8_IN_PROJ and act == torch.bfloat16 and ops.fp8_proj_supported(x2d, Dm):
             # fp8 matrix cores: per-token e4m3 activations x per-row e4m3 weights, fp32 accumulation, bf16 channel-major output
             wq, sw = cache["w_in_fp8"] if (cache and "w_in_fp8" in cache) else ops.quant_weight_fp8(W_in)
-            xq, sx = ops.quant_rows_fp8(x2d)
+            # e4m3 activations + per-token scales: written by the add + norm kernel that produced x2d (fp8_act), else quantised here
+            xq, sx = (fp8_act[0].view(T, Dm), fp8_act[1]) if fp8_act is not None else ops.quant_rows_fp8(x2d)
             xz = ops.proj_wxT_fp8(wq, sw, xq, sx).view(2 * E, SB, Lq)
         elif ops.proj_supported(x2d, Dm):  # bf16: our W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
             xz = ops.proj_wxT(w_in, x2d).view(2 * E, SB, Lq)
@@ -409,7 +414,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             dxz[E:].add_(dz_r)
         dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
         dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
-        return (dx2d, None, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
+        return (dx2d, None, None, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
 
 
 def can_use(mamba_fwd, mamba_rev, strategy) -> bool:
@@ -430,6 +435,7 @@ def bimamba_mixer(hn: torch.Tensor, mamba_fwd, mamba_rev, split: int) -> torch.T
     cache = _cached(mamba_fwd, [mamba_fwd.in_proj.weight, mamba_fwd.out_proj.weight, mamba_fwd.x_proj.weight,
                                 mamba_fwd.dt_proj.weight, mamba_rev.x_proj.weight, mamba_rev.dt_proj.weight,
                                 mamba_fwd.A_log, mamba_rev.A_log])
-    out = BiMambaMixerFn.apply(hn.reshape(S * B * Lq, Dm), S * B, Lq, split, cache, mamba_fwd.in_proj.weight,
+    fp8_act = getattr(hn, "_cad_fp8", None) if (_FP8_IN_PROJ and hn.is_contiguous()) else None  # (ops.add_norm attaches it)
+    out = BiMambaMixerFn.apply(hn.reshape(S * B * Lq, Dm), S * B, Lq, split, cache, fp8_act, mamba_fwd.in_proj.weight,
                                mamba_fwd.out_proj.weight, *ps)
     return out.view(S, B, Lq, Dm)

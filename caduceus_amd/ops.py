@@ -74,9 +74,13 @@ def embed(ids: torch.Tensor, weight: torch.Tensor, comp: Optional[torch.Tensor],
 # ------------------------------------------------------------------------------------------------------------------
 # fused add + norm
 # ------------------------------------------------------------------------------------------------------------------
+# set by mixer.set_fp8_in_proj: add_norm also emits the e4m3 copy of the normed activations (cad_add_norm_args.y_fp8 / y_scale)
+FP8_ACTIVATIONS = False
+
+
 class _AddNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype):
+    def forward(ctx, x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype, want_fp8=False):
         x = x.contiguous()
         S, D = x.shape[0], x.shape[-1]
         rows = x.numel() // (S * D)
@@ -89,18 +93,23 @@ class _AddNorm(torch.autograd.Function):
         res_out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         rstd = torch.empty((S * rows,), dtype=torch.float32, device=x.device)
         mean = None if is_rms else torch.empty((S * rows,), dtype=torch.float32, device=x.device)
-        stream = L.stream_and_check(x, res, w, b, y, res_out, rstd, mean)
+        yq = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_fp8 else None
+        ys = torch.empty((S * rows,), dtype=torch.float32, device=x.device) if want_fp8 else None
+        stream = L.stream_and_check(x, res, w, b, y, res_out, rstd, mean, yq, ys)
         a = L.AddNormArgs(L.ptr(x), L.ptr(res), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(res_out), L.ptr(rstd), L.ptr(mean),
                           rows, S, D, float(eps), int(is_rms), int(swap_flip), L.dtype_code(x.dtype),
-                          L.dtype_code(y_dtype))
+                          L.dtype_code(y_dtype), L.ptr(yq), L.ptr(ys))
         L.check(L.get_lib().cad_add_norm_fwd(C.byref(a), stream), "cad_add_norm_fwd")
         ctx.save_for_backward(res_out, rstd, mean, w)
         ctx.meta = (rows, S, D, is_rms, swap_flip, x.dtype, y_dtype, residual is not None, bias is not None,
                     weight.dtype)
+        if want_fp8:
+            ctx.mark_non_differentiable(yq, ys)
+            return y, res_out, yq, ys
         return y, res_out
 
     @staticmethod
-    def backward(ctx, dy, dres_out):
+    def backward(ctx, dy, dres_out, *_unused):
         res_out, rstd, mean, w = ctx.saved_tensors
         rows, S, D, is_rms, swap_flip, x_dtype, y_dtype, has_res, has_bias, wdt = ctx.meta
         dy = dy.contiguous()
@@ -114,7 +123,7 @@ class _AddNorm(torch.autograd.Function):
                              L.ptr(dres_in), L.ptr(dw), L.ptr(db), rows, S, D, int(is_rms), int(swap_flip),
                              L.dtype_code(x_dtype), L.dtype_code(y_dtype))
         L.check(L.get_lib().cad_add_norm_bwd(C.byref(a), stream), "cad_add_norm_bwd")
-        return dx, dres_in, dw.to(wdt), (None if db is None else db.to(wdt)), None, None, None, None
+        return dx, dres_in, dw.to(wdt), (None if db is None else db.to(wdt)), None, None, None, None, None
 
 
 def add_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -123,6 +132,13 @@ def add_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Te
     strands at once, with the reference's fused-path strand swap as an index map when `swap_flip`."""
     if swap_flip and x.shape[0] != 2:
         raise ValueError("swap_flip needs two strands")
+    if FP8_ACTIVATIONS and y_dtype == torch.bfloat16 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 512 and \
+            bool(L.get_lib().cad_proj_fp8_supported(int(x.shape[-1]))):
+        # configs[4]: the in_proj that consumes this tensor runs on the fp8 matrix cores -- its e4m3 operand (+ per-token scales) is
+        # written by this kernel's epilogue and travels with the tensor (mixer.bimamba_mixer picks it up; anything else ignores it)
+        y, res, yq, ys = _AddNorm.apply(x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype, True)
+        y._cad_fp8 = (yq, ys)
+        return y, res
     return _AddNorm.apply(x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype)
 
 

@@ -100,6 +100,12 @@ typedef struct {
     float eps;
     int is_rms, swap_flip;
     int x_dtype, y_dtype;
+    /* optional (NULL = absent): an e4m3 copy of y with one scale per output row, y ~ y_fp8 * y_scale[row] -- the operand of the fp8
+     * in_proj (cad_proj_wxT_fp8) written by the kernel that produces the normed activations instead of a separate
+     * cad_quant_rows_fp8 pass over them (to which it is bit-identical).  y_fp8: (S, R, D) bytes, y_scale: (S * R) fp32, both in the
+     * OUTPUT index space.  D % 4 == 0, D <= 512, 16-byte aligned tensors. */
+    void* y_fp8;
+    float* y_scale;
 } cad_add_norm_args;
 int cad_add_norm_fwd(const cad_add_norm_args* a, void* stream);
 /* Backward.  dy (y_dtype) and dres_out (fp32, may be NULL) are in the OUTPUT index space, sum_saved/rstd/mean

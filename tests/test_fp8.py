@@ -49,3 +49,49 @@ def test_fp8_in_proj_in_the_model(backend):
     k = "caduceus.backbone.layers.0.mixer.submodule.mamba_fwd.out_proj.weight"
     e = float((ga[k] - gbase[k]).norm() / gbase[k].norm())
     assert e < 0.2, e
+
+
+@pytest.mark.parametrize("D,swap", [(256, True), (512, True), (256, False)])
+def test_add_norm_writes_the_e4m3_operand_of_the_in_proj(backend, D, swap):
+    """configs[4]: the e4m3 activations + per-token scales of the fp8 in_proj are an EPILOGUE of add + norm (cad_add_norm_args.y_fp8 /
+    y_scale) -- bit-identical to cad_quant_rows_fp8 of the stored bf16 tensor, strand swap included, with no pass of their own."""
+    from caduceus_amd import ops
+    name, dev = backend
+    g = torch.Generator().manual_seed(5)
+    S, rows = (2, 37) if swap else (1, 50)
+    x = torch.randn(S, 1, rows, D, generator=g).to(dev).to(torch.bfloat16)
+    x[0, 0, 3] = 0  # an all-zero row (scale 1) ...
+    res = torch.randn(S, 1, rows, D, generator=g).to(dev)
+    res[0, 0, 3] = 0
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    try:
+        mixer.set_fp8_in_proj(True)
+        y, r = ops.add_norm(x, res, w, None, 1e-5, True, swap, torch.bfloat16)
+    finally:
+        mixer.set_fp8_in_proj(False)
+    y0, r0 = ops.add_norm(x, res, w, None, 1e-5, True, swap, torch.bfloat16)
+    assert torch.equal(y, y0) and torch.equal(r, r0) and not hasattr(y0, "_cad_fp8")
+    yq, ys = y._cad_fp8
+    q_ref, s_ref = ops.quant_rows_fp8(y.reshape(-1, D))
+    assert torch.equal(yq.reshape(-1, D), q_ref) and torch.equal(ys, s_ref)
+    assert float(ys.min()) > 0
+
+
+def test_fp8_model_step_takes_the_producer_written_operand(backend, monkeypatch):
+    """With the fp8 in_proj on, no separate quantisation pass runs in the model: every mixer picks up what add + norm wrote."""
+    from caduceus_amd import ops
+    name, dev = backend
+    model = _model(dev)
+    ids = torch.randint(7, 11, (1, 64), generator=torch.Generator().manual_seed(2)).to(dev)
+    calls = []
+    real = ops.proj_wxT_fp8
+    monkeypatch.setattr(ops, "quant_rows_fp8", lambda *a, **k: (_ for _ in ()).throw(AssertionError("separate quantisation pass")))
+    monkeypatch.setattr(ops, "proj_wxT_fp8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    try:
+        mixer.set_fp8_in_proj(True)
+        with torch.autocast(dev.type, dtype=torch.bfloat16):
+            out = model(ids, labels=ids)
+        out.loss.backward()
+    finally:
+        mixer.set_fp8_in_proj(False)
+    assert len(calls) == 1 and torch.isfinite(out.loss)
