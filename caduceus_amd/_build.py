@@ -42,9 +42,16 @@ def scan_source_hash() -> str:
     around them (bench.py compares it with the `scan_src` recorded in profiles/r03_scan_pmc.json)."""
     import hashlib
     h = hashlib.sha256()
-    for f in [os.path.join(CSRC, n) for n in SCAN_SOURCES] + [os.path.join(HERE, "..", "include", "caduceus_hip.h")]:
+    for f in [os.path.join(CSRC, n) for n in SCAN_SOURCES]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
+    # of the C-ABI header only the scan section (cad_scan_args / cad_scan_bwd_args and their entry points): a new field of another
+    # kernel's argument struct does not change the scans' code
+    hdr = open(os.path.join(HERE, "..", "include", "caduceus_hip.h")).read()
+    a, b = hdr.find(" * Selective SSM scan"), hdr.find(" * Dense projections of the mixer")
+    assert 0 <= a < b, "include/caduceus_hip.h: scan section markers not found"
+    h.update(b"caduceus_hip.h[scan]")
+    h.update(hdr[a:b].encode())
     return h.hexdigest()[:12]
 
 

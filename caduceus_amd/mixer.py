@@ -98,6 +98,21 @@ def _wgrad_cm_cm(a_cm: torch.Tensor, b_cm: torch.Tensor) -> torch.Tensor:
                      dtype=torch.float32)
 
 
+def _own_wgrad_chunked_ok(X: torch.Tensor, M: int) -> bool:
+    """Reductions over ALL tokens with K = d_inner > 512 rows (d_model 512: configs[4]): the own weight-gradient kernel takes 512 rows of
+    X per launch, so X is cut into row blocks -- the rows of dW are independent."""
+    K, T = X.shape
+    return K > 512 and K % 512 == 0 and ops.proj_wgrad_only_supported(X, M, 512, T)
+
+
+def _own_wgrad_chunked(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """dW (M, K) fp32 = Y (M, T) @ X (K, T)^T with fp32 accumulation over all tokens (cad_proj_wx_wgrad's weight-gradient stage), K in
+    blocks of 512 rows.  Replaces the K-split library bmm whose bf16-rounded partial products cost 3-4 % relative error on
+    dW_x of a d_model 512 layer (found by tests/test_configs.py::test_config4_one_layer_d512_L262144_every_gradient_vs_oracle)."""
+    K = X.shape[0]
+    return torch.cat([ops.proj_wgrad_only(X[h:h + 512], Y) for h in range(0, K, 512)], dim=1)
+
+
 def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
     """a (M, T) channel-major @ b (T, N) token-major -> (M, N) fp32."""
     M, T = a_cm.shape
@@ -379,12 +394,17 @@ class BiMambaMixerFn(torch.autograd.Function):
                     ops.proj_wx(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
                 else:
                     torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
-                dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
+                if _OWN_DWX and _own_wgrad_chunked_ok(ddelta.view(E, T), R):
+                    dW_dt = _own_wgrad_chunked(ddelta.view(E, T), dbc[:R].view(R, T)).t()
+                else:
+                    dW_dt = _wgrad_cm_cm(ddelta.view(E, T), dbc[:R].view(R, T))
             if _OWN_DWX and ops.proj_wgrad_only_supported(xc, R + 2 * N, E, T):
                 if wg_x is None:
                     wg_x = ops.wgrad_partials(T, E, R + 2 * N, xc.device, nsets=2)
                 ops.proj_wgrad_only(xc.view(E, T), ddbc.view(R + 2 * N, T), part=wg_x[i])
                 dW_x = None
+            elif _OWN_DWX and _own_wgrad_chunked_ok(xc.view(E, T), R + 2 * N):
+                dW_x = _own_wgrad_chunked(xc.view(E, T), ddbc.view(R + 2 * N, T))
             else:
                 dW_x = _wgrad_cm_cm(ddbc.view(R + 2 * N, T), xc.view(E, T))
             # d(xc) = du + W_x^T . d(dbc), in place (no copy of the 268 MB addend)
