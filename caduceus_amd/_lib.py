@@ -52,6 +52,10 @@ class Conv1dArgs(C.Structure):
                 ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
 
 
+class ReduceJob(C.Structure):
+    _fields_ = [("src", _p), ("dst", _p)]
+
+
 class ProjTmArgs(C.Structure):
     _fields_ = [("W", _p), ("X", _p), ("X2", _p), ("out", _p), ("T", _i64), ("M", _i), ("K", _i), ("ldw", _i64), ("ldx", _i64),
                 ("ldo", _i64)]
@@ -132,6 +136,7 @@ SYMBOLS = {
     "cad_scan_fwd_multi": (_i, [C.POINTER(ScanArgs), _i, _p]),
     "cad_scan_bwd_multi": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_reduce_partials": (_i, [_p, _i, _i64, _p, _i, _p]),
+    "cad_reduce_partials_multi": (_i, [C.POINTER(ReduceJob), _i, _i, _i64, _i, _p]),
     "cad_scan_bwd_partials": (_i, [_i]),
     "cad_scan_bwd_gate_fix": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_scan_gate_fix_entries": (_i64, [_i, _i64, _i64]),

@@ -735,6 +735,27 @@ __global__ void reduce_partials_kernel(const T* src, int nparts, int64_t n, T* d
     }
 }
 
+// several folds of the same depth and length in one launch (blockIdx.y = job): the dB and dC slots of both parameter sets of a layer
+struct ReduceJobs {
+    const void* src[CAD_REDUCE_MAX_JOBS];
+    void* dst[CAD_REDUCE_MAX_JOBS];
+};
+template <typename T>
+__global__ void reduce_partials_multi_kernel(ReduceJobs jobs, int nparts, int64_t n) {
+    const T* src = (const T*)jobs.src[blockIdx.y];
+    T* dst = (T*)jobs.dst[blockIdx.y];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {  // (n % 4 == 0, 16-byte aligned: checked)
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nparts; ++k) {
+            float x[4];
+            ld4p<T>(src + (int64_t)k * n + i, x);
+            s[0] += x[0], s[1] += x[1], s[2] += x[2], s[3] += x[3];
+        }
+        cad_cvt_store<T, 4>(dst + i, s);
+    }
+}
+
 }  // namespace
 
 SC_TIME_EXPORT(cad_debug_timing_bwd)
@@ -842,6 +863,35 @@ extern "C" int cad_reduce_partials(const void* src, int n_partials, int64_t n, v
         CAD_LAUNCH((reduce_partials_kernel<float>), grid, block, 0, stream, (const float*)src, n_partials, n, (float*)dst, vec);
     else if (dst_dtype == CAD_BF16)
         CAD_LAUNCH((reduce_partials_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, n_partials, n, (bf16_t*)dst, vec);
+    else
+        return CAD_ERR_UNSUPPORTED;
+    return cad_after_launch();
+}
+
+extern "C" int cad_reduce_partials_multi(const cad_reduce_job* jobs, int njobs, int n_partials, int64_t n, int dst_dtype, void* stream) {
+    CAD_CHECK_ARG(jobs && njobs >= 1 && njobs <= CAD_REDUCE_MAX_JOBS && n_partials >= 1 && n > 0);
+    ReduceJobs kj;
+    bool vec = (n % 4) == 0;
+    for (int i = 0; i < CAD_REDUCE_MAX_JOBS; ++i) {
+        const cad_reduce_job& j = jobs[i < njobs ? i : 0];
+        CAD_CHECK_ARG(j.src && j.dst);
+        kj.src[i] = j.src, kj.dst[i] = j.dst;
+        vec = vec && (((uintptr_t)j.src | (uintptr_t)j.dst) % 16) == 0;
+    }
+    if (!vec) {  // ragged / unaligned: one plain fold per job
+        for (int i = 0; i < njobs; ++i) {
+            const int rc = cad_reduce_partials(jobs[i].src, n_partials, n, jobs[i].dst, dst_dtype, stream);
+            if (rc != CAD_OK) return rc;
+        }
+        return CAD_OK;
+    }
+    int64_t nb = (n / 4 + 255) / 256 + 1;
+    if (nb > 16384) nb = 16384;
+    dim3 grid((unsigned)nb, (unsigned)njobs), block(256);
+    if (dst_dtype == CAD_F32)
+        CAD_LAUNCH((reduce_partials_multi_kernel<float>), grid, block, 0, stream, kj, n_partials, n);
+    else if (dst_dtype == CAD_BF16)
+        CAD_LAUNCH((reduce_partials_multi_kernel<bf16_t>), grid, block, 0, stream, kj, n_partials, n);
     else
         return CAD_ERR_UNSUPPORTED;
     return cad_after_launch();

@@ -369,18 +369,24 @@ class BiMambaMixerFn(torch.autograd.Function):
         _keep = ops.scan_bwd_launch(lib, args, 2, stream, k, seg_P, dirs, split)
         L.check(lib.cad_scan_bwd_gate_fix(args, 2, stream), "cad_scan_bwd_gate_fix")  # no-op unless some z == 0 exactly
         grads, dxcs, part = [], [], []
+        # the dB / dC partial slots of BOTH sets are folded by one launch (four folds: cad_reduce_partials_multi), straight into the
+        # rows of each set's x_proj gradient operand
+        ddbcs = [torch.empty_like(sets[i][3]) for i in range(2)]
+        jobs = (L.ReduceJob * 4)()
+        for i in range(2):
+            N_, R_ = sets[i][2].shape[1], sets[i][3].shape[0] - 2 * sets[i][2].shape[1]
+            dBC_ = work[i][5]
+            jobs[2 * i] = L.ReduceJob(L.ptr(dBC_[0]), L.ptr(ddbcs[i][R_:R_ + N_]))
+            jobs[2 * i + 1] = L.ReduceJob(L.ptr(dBC_[1]), L.ptr(ddbcs[i][R_ + N_:]))
+        L.check(lib.cad_reduce_partials_multi(jobs, 4, work[0][6], sets[0][2].shape[1] * SB * Lq, L.dtype_code(act), stream),
+                "cad_reduce_partials_multi")
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
             du, ddelta, dA, dD, dbias, dBC, npart = work[i]
             N = A.shape[1]
             R = dbc.shape[0] - 2 * N
             # gradient of [dt_lr ; B ; C] assembled in place: rows [R:] by the partial-slot reduction, rows [:R] by a GEMM
-            ddbc = torch.empty_like(dbc)
-            n = N * SB * Lq
-            L.check(lib.cad_reduce_partials(L.ptr(dBC[0]), npart, n, L.ptr(ddbc[R:R + N]), L.dtype_code(act), stream),
-                    "cad_reduce_partials")
-            L.check(lib.cad_reduce_partials(L.ptr(dBC[1]), npart, n, L.ptr(ddbc[R + N:]), L.dtype_code(act), stream),
-                    "cad_reduce_partials")
+            ddbc = ddbcs[i]
             if _FUSED_WGRAD and ops.proj_wx_wgrad_supported(ddelta, R, E, T):
                 # d(dt_lr) = W_dt^T d(delta) and dW_dt = d(delta) dt_lr^T from ONE pass over d(delta) (cad_proj_wx_wgrad); the
                 # partial slots of both parameter sets are folded by one sum after the loop

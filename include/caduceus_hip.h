@@ -276,6 +276,14 @@ int64_t cad_scan_gate_fix_entries(int E, int64_t SB, int64_t L);
 int cad_scan_bwd_partials(int E);
 /* dst[i] = sum_k src[k*n + i], k < n_partials (fp32 accumulation); src and dst in dtype (fp32 or bf16). */
 int cad_reduce_partials(const void* src, int n_partials, int64_t n, void* dst, int dtype, void* stream);
+/* The same fold for up to CAD_REDUCE_MAX_JOBS (src, dst) pairs of equal depth, length and dtype in ONE launch -- the dB and dC slots of
+ * both parameter sets of a BiMamba layer (four folds per layer; same summation order as the single fold: bit-identical results). */
+#define CAD_REDUCE_MAX_JOBS 4
+typedef struct {
+    const void* src;
+    void* dst;
+} cad_reduce_job;
+int cad_reduce_partials_multi(const cad_reduce_job* jobs, int njobs, int n_partials, int64_t n, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Dense projections of the mixer on the matrix cores (bf16 MFMA, fp32 accumulation).   Replace the `in_proj` /

@@ -567,3 +567,26 @@ def test_kernel_timer_counts_only_the_enabled_kinds(backend):
         CL.prof_enable(False)
         CL.prof_reset()
 
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,npart", [(4096, 7), (16 * 3 * 200, 64), (1030, 3)])
+def test_reduce_partials_multi_equals_the_single_folds(backend, dtype, n, npart):
+    """cad_reduce_partials_multi: up to four folds in one launch, the same summation order as cad_reduce_partials (bit-identical),
+    including the ragged fallback (n % 4 != 0)."""
+    import ctypes
+    from caduceus_amd import _lib as CL
+    name, dev = backend
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randn(npart, n, generator=g).to(dev).to(dtype) for _ in range(4)]
+    single = [torch.empty(n, dtype=dtype, device=dev) for _ in range(4)]
+    multi = [torch.empty(n, dtype=dtype, device=dev) for _ in range(4)]
+    stream = CL.stream_and_check(*srcs, *single, *multi)
+    jobs = (CL.ReduceJob * 4)()
+    for i in range(4):
+        CL.check(CL.get_lib().cad_reduce_partials(CL.ptr(srcs[i]), npart, n, CL.ptr(single[i]), CL.dtype_code(dtype), stream), "single")
+        jobs[i] = CL.ReduceJob(CL.ptr(srcs[i]), CL.ptr(multi[i]))
+    CL.check(CL.get_lib().cad_reduce_partials_multi(jobs, 4, npart, n, CL.dtype_code(dtype), stream), "multi")
+    for i in range(4):
+        assert torch.equal(single[i], multi[i])
+        torch.testing.assert_close(single[i].float().cpu(), srcs[i].float().sum(0).cpu(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-5,
+                                   atol=5e-2 if dtype == torch.bfloat16 else 1e-4)
