@@ -198,9 +198,60 @@ def pmc_quotable(pmc: dict, lib_version: str):
     return None
 
 
+def scan_floor_worker(d_model, seqlen, strands, batch, reps=4):
+    """Runs in a child process whose CADUCEUS_AMD_LIB is the arithmetic-only timing build (caduceus_amd/_build.py::build_floor): ONE
+    production mixer layer (forward + backward, exactly as the training step launches it) at the benchmark's layer shape, the two scan
+    kinds timed by the library's HIP events.  Prints {"scan_fwd_ms": .., "scan_bwd_ms": ..} per scan OPERATION of a layer."""
+    from caduceus_amd import _lib, mixer
+    from caduceus_amd.mamba import Mamba
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    mf, mr = Mamba(d_model, device=dev), Mamba(d_model, device=dev)
+    mr.in_proj.weight = mf.in_proj.weight
+    mr.out_proj.weight = mf.out_proj.weight
+    hn = torch.randn(strands, batch, seqlen, d_model, device=dev).to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(strands, batch, seqlen, d_model, device=dev).to(torch.bfloat16)
+    split = batch if strands == 2 else strands * batch
+
+    def step():
+        for p in list(mf.parameters()) + list(mr.parameters()):
+            p.grad = None
+        hn.grad = None
+        mixer.prepare_step_cache([(mf, mr)], torch.bfloat16)
+        mixer.bimamba_mixer(hn, mf, mr, split).backward(g)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True, kinds=("scan_fwd", "scan_bwd"))
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    pr = _lib.prof_read()
+    print(json.dumps({"lib": _lib.version(), "scan_fwd_ms": pr["scan_fwd"][0] / reps, "scan_bwd_ms": pr["scan_bwd"][0] / reps}), flush=True)
+
+
+def scan_floor(d_model, seqlen, strands, batch):
+    """{"scan_fwd_ms", "scan_bwd_ms"} of the arithmetic-only build on this GPU, or None when that library has not been built."""
+    import subprocess
+    from caduceus_amd import _build
+    if not os.path.exists(_build.FLOOR_LIB):
+        return None
+    env = dict(os.environ, CADUCEUS_AMD_LIB=_build.FLOOR_LIB)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--scan-floor-worker", str(d_model), str(seqlen), str(strands),
+                          str(batch)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=False)
+    if out.returncode != 0:
+        return {"error": out.stderr.decode()[-300:]}
+    return json.loads(out.stdout.decode().strip().splitlines()[-1])
+
+
 def main():
     if len(sys.argv) >= 2 and sys.argv[1] == "--cpu-baseline-worker":
         cpu_baseline_worker(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        return
+    if len(sys.argv) >= 6 and sys.argv[1] == "--scan-floor-worker":
+        scan_floor_worker(*[int(v) for v in sys.argv[2:6]])
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +270,7 @@ def main():
     ap.add_argument("--fp8-proj", action="store_true",
                     help="configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores -- per-token activation scales, per-row weight "
                          "scales, fp32 accumulation (csrc/gemm_fp8.hip); everything else stays bf16")
+    ap.add_argument("--no-floor", action="store_true", help="skip the arithmetic-only scan timing (roofline.arithmetic_floor)")
     ap.add_argument("--model", default="ps", choices=["ps", "ph"],
                     help="ps: RCPS (configs[2..4], the headline); ph: no RCPS wrapper, RC augmentation is a data-side flip "
                          "(configs[1], run with --seqlen 1024 --batch 128)")
@@ -437,6 +489,19 @@ def main():
             proj = {"error": repr(ex)}
         if roofline is not None:
             roofline["projections"] = proj
+            # third ceiling: the scans' arithmetic-only timing build on THIS GPU, same launch shape and power state
+            floor = None
+            if world == 1 and not emu and args.dtype == "bf16" and not args.no_floor:
+                try:
+                    floor = scan_floor(args.d_model, args.seqlen, 2 if args.model == "ps" else 1, args.batch)
+                except Exception as ex:  # evidence only
+                    floor = {"error": repr(ex)}
+            if floor and "scan_bwd_ms" in floor:
+                floor["kernel_over_floor"] = {k: kinds[k]["avg_ms"] / floor[k + "_ms"] for k in kinds if floor.get(k + "_ms")}
+                floor["note"] = ("libcaduceus_hip_floor.so = the same sources with -DSC_WHATIF=14434 (SC_WHATIF_ARITH_ONLY: no global stores, no "
+                                 "dB/dC slab or flush, no B/C tile loads / conversion / LDS traffic, no barrier): one production mixer layer "
+                                 "in a child process right after the timed region; per scan operation of a layer")
+            roofline["arithmetic_floor"] = floor
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             try:

@@ -83,5 +83,18 @@ def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = 
     return out
 
 
+FLOOR_LIB = os.path.join(HERE, "libcaduceus_hip_floor.so")
+FLOOR_DEFINES = ("SC_WHATIF=14434",)  # = SC_WHATIF_ARITH_ONLY (scan_common.h)
+
+
+def build_floor(force: bool = False) -> str:
+    """The scans' "stripped timing build" (VERDICT r3 item 1): the same library with the scan kernels reduced to their input stream and
+    arithmetic (no stores, no dB / dC slab or flush, no B / C tiles, no barrier; WRONG results by construction).  bench.py times one
+    layer's scan launches on it next to the real ones and reports kernel / floor in `roofline.arithmetic_floor`.  Never loaded by the
+    product: only through CADUCEUS_AMD_LIB in bench.py's floor worker."""
+    return build_hip(force=force, verbose=False, defines=FLOOR_DEFINES, out=FLOOR_LIB)
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv))
+    print(build_floor(force="--force" in sys.argv))

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
     const int64_t total = nmine * NCH;
     char* wl = smem + C::RING * C::XBUF;
     constexpr int WSTR = K * 2 + 16;
-    char* yt = wl + MB * 16 * WSTR;
+    char* yt = wl + (PROD ? MB * 16 * WSTR : 0);  // (the weight-gradient-only form keeps no W copy: M = 64 at K = 512 would not fit otherwise)
     auto issue = [&](int64_t it) {
         const int64_t blk = b0 + (it / NCH) * bstep;
         gt_issue_chunk(X, a.ldx, (int)(it % NCH) * C::KC, blk * C::NT, T, smem + (int)(it % C::RING) * C::XBUF, wave, lane);
@@ -899,12 +899,20 @@ extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
     return a->K <= 32 ? launch_wx<1>(a, stream) : launch_wx<2>(a, stream);
 }
 
+static size_t gt_wgrad_lds(int M, int K, bool prod) {
+    const int mb = (M + 15) / 16;
+    size_t lds = (prod ? GtCfg::lds(mb * 16, K) : (size_t)GtCfg::RING * GtCfg::XBUF) + 2 * (size_t)mb * 16 * GtCfg::XROW;
+    const size_t exch = (size_t)4 * (K / GtCfg::KC) * mb * 1024;
+    return lds < exch ? exch : lds;
+}
 extern "C" int cad_proj_wx_wgrad_supported(int M, int K, int64_t T) {
-    return (M == 16 || M == 32) && (K == 256 || K == 512) && T >= GtCfg::NT && (T % GtCfg::NT) == 0;
+    return (M == 16 || M == 32) && (K == 256 || K == 512) && T >= GtCfg::NT && (T % GtCfg::NT) == 0 &&
+           gt_wgrad_lds(M, K, true) <= 160 * 1024;
 }
 // the weight gradient alone (cad_proj_args.W == NULL, out == NULL): any M <= 64
 extern "C" int cad_proj_wgrad_only_supported(int M, int K, int64_t T) {
-    return M >= 1 && M <= 64 && (K == 256 || K == 512) && T >= GtCfg::NT && (T % GtCfg::NT) == 0;
+    return M >= 1 && M <= 64 && (K == 256 || K == 512) && T >= GtCfg::NT && (T % GtCfg::NT) == 0 &&
+           gt_wgrad_lds(M, K, false) <= 160 * 1024;
 }
 extern "C" int cad_proj_wx_wgrad_partials(int64_t T) {
     const int64_t nblk = T / GtCfg::NT;
@@ -914,9 +922,10 @@ extern "C" int cad_proj_wx_wgrad_partials(int64_t T) {
 template <int MB, int NCH, bool PROD>
 static int launch_wx_wgrad(const cad_proj_args* a, void* stream) {
     const int gx = cad_proj_wx_wgrad_partials(a->T);
-    size_t lds = GtCfg::lds(MB * 16, NCH * GtCfg::KC) + 2 * (size_t)MB * 16 * GtCfg::XROW;
+    size_t lds = (PROD ? GtCfg::lds(MB * 16, NCH * GtCfg::KC) : (size_t)GtCfg::RING * GtCfg::XBUF) + 2 * (size_t)MB * 16 * GtCfg::XROW;
     const size_t exch = (size_t)4 * NCH * MB * 1024;  // the final exchange of the accumulator tiles reuses the front of the LDS
     if (lds < exch) lds = exch;
+    if (lds > 160 * 1024) return CAD_ERR_UNSUPPORTED;  // (the *_supported predicates exclude these shapes)
     dim3 grid((unsigned)gx), block(64 * GP_WAVES);
     GP_BIG_LDS((proj_wx_thin_wgrad_kernel<MB, NCH, PROD>), lds);
     CAD_LAUNCH((proj_wx_thin_wgrad_kernel<MB, NCH, PROD>), grid, block, lds, stream, *a);

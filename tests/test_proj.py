@@ -148,7 +148,7 @@ def test_proj_wx_wgrad_fused(backend, M, K, T):
     torch.testing.assert_close(dW.cpu().double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("M,K,T", [(48, 512, 128 * 70), (40, 256, 128 * 5), (24, 512, 128 * 300), (64, 256, 128 * 9), (7, 512, 128)])
+@pytest.mark.parametrize("M,K,T", [(48, 512, 128 * 70), (40, 256, 128 * 5), (24, 512, 128 * 300), (64, 256, 128 * 9), (7, 512, 128), (64, 512, 256)])
 def test_proj_wgrad_only(backend, M, K, T):
     """cad_proj_wx_wgrad with W == NULL: dW = Y . X^T alone (dW_x = d(dbc) . xc^T of the x_proj backward), any M <= 64, against the
     fp64 product of the same bf16 operands."""
