@@ -3,7 +3,7 @@ an idea is being measured): copies caduceus_amd/csrc + include/ to a scratch tre
 caduceus_amd/libcaduceus_hip_<name>.so (git-ignored; it travels to the GPU box with gpurun) and leaves the product library alone.
 
     python tools/exp_variants.py base nt_proj_x_loads ...      # build
-    gpurun -- 'bash tools/ab_bench_libs.sh 2 base nt_proj_x_loads'   # same-box A/B of the whole training step
+    gpurun -- 'bash tools/gpu_ab.sh 2 base nt_proj_x_loads'   # same-box A/B of one production layer (tools/layer_bench.py)
 
 An edit is (file, old text, new text); `old` must occur exactly once (prefix __ALL__: every occurrence).  Adopt a winner by making the same edit in csrc/ (then the usual
 evidence: GPU suite, bench, and -- if a scan source changed -- tools/prof_scan.sh + tools/make_scan_pmc_json.py)."""
@@ -54,7 +54,7 @@ def build(name):
         else:
             assert s.count(old) == 1, f"{name}: `{old[:60]}` occurs {s.count(old)} times in {fname}"
         open(p, "w").write(s.replace(old, new))
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-pass-failed",
              f'-DCAD_SRC_HASH="exp-{name}"']
     procs = []
     for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))):
