@@ -513,7 +513,9 @@ def main():
             "metric": "DNA tokens/sec (whole node), hg38-style MLM pre-train step", "value": tokens / elapsed,
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
-            "vs_baseline": None, "dtype": args.dtype + (" (in_proj: fp8 e4m3 MFMA, fp32 accumulate)" if args.fp8_proj else ""),
+            "vs_baseline": None, "dtype": args.dtype + (" (in_proj forward: e4m3 activations [per-token scales, written by the add + norm epilogue] x e4m3 weights "
+                                            "[per-row scales] on v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulate; every other operand and the "
+                                            "whole backward bf16)" if args.fp8_proj else ""),
             "data": "synthetic" + (" (host emulator: not a measurement)" if emu else ""),
             "config": {"workload": f"Caduceus-{args.model.upper() if args.model == 'ps' else 'Ph'} d_model={args.d_model} "
                                    f"n_layer={args.n_layer} seqlen={args.seqlen} rcps={'true' if args.model == 'ps' else 'false'} "

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-end evidence on ONE box: the GPU parity suite, smoke(), counter + trace profiles of the scans (-> profiles/r04_scan_pmc.json,
-# stamped with cad_version()), the whole-step kernel trace, and the default bench line.
+# stamped with cad_version()), the whole-step kernel trace, the default bench line and the other configurations' bench lines.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_final.log 2>&1; grep -n "passed\|failed" gpurun_out/pytest_gpu_final.log | tail -2
+timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_final.log 2>&1; grep -n "passed\|failed" gpurun_out/pytest_gpu_final.log | tail -2; grep -n "^FAILED\|^ERROR" gpurun_out/pytest_gpu_final.log | head
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 rm -rf gpurun_out/prof; timeout 900 bash tools/prof_scan.sh > gpurun_out/prof_scan.log 2>&1
-python tools/make_scan_pmc_json.py gpurun_out/prof gpurun_out/scan_pmc.json 2>&1 | tail -1 | cut -c1-600
-python tools/summarize_prof.py gpurun_out/prof > gpurun_out/prof_summary.txt 2>&1; grep -n "scan_bwd_kernel\|scan_fwd_kernel" gpurun_out/prof_summary.txt | head -4 | cut -c1-260
+python tools/make_scan_pmc_json.py gpurun_out/prof gpurun_out/scan_pmc.json 2>&1 | tail -1 | cut -c1-400
+python tools/summarize_prof.py gpurun_out/prof > gpurun_out/prof_summary.txt 2>&1; grep -n "scan_bwd_kernel\|scan_fwd_kernel" gpurun_out/prof_summary.txt | head -2 | cut -c1-260
 timeout 600 bash tools/prof_step.sh 2>&1 | tail -1 | cut -c1-200
 python - <<'PY'
 import csv, glob
@@ -26,3 +26,11 @@ if f:
 PY
 cp gpurun_out/scan_pmc.json profiles/r04_scan_pmc.json  # (on the box: the bench line below quotes the counters taken on THIS build)
 timeout 400 python bench.py > gpurun_out/bench_final.log 2>gpurun_out/bench_final.err; tail -1 gpurun_out/bench_final.log | cut -c1-400
+if [ "$1" = all ]; then
+timeout 300 python bench.py --model ph --seqlen 1024 --batch 128 --cpu-sample 0 --no-floor > gpurun_out/bench_c2_ph_L1024_b128.log 2>/dev/null; tail -1 gpurun_out/bench_c2_ph_L1024_b128.log | cut -c1-200
+timeout 300 python bench.py --model ph --cpu-sample 0 > gpurun_out/bench_ph_L131072.log 2>/dev/null; tail -1 gpurun_out/bench_ph_L131072.log | cut -c1-200
+timeout 400 python bench.py --d-model 512 --seqlen 262144 --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/bench_c4shape_bf16_1gpu.log 2>/dev/null; tail -1 gpurun_out/bench_c4shape_bf16_1gpu.log | cut -c1-200
+timeout 400 python bench.py --d-model 512 --seqlen 262144 --steps 3 --warmup 1 --cpu-sample 0 --fp8-proj > gpurun_out/bench_c4shape_fp8_1gpu.log 2>/dev/null; tail -1 gpurun_out/bench_c4shape_fp8_1gpu.log | cut -c1-200
+CADUCEUS_DP_FORCE_COLLECTIVE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --cpu-sample 0 --no-floor > gpurun_out/bench_torchrun_1rank_rccl.log 2>/dev/null; tail -1 gpurun_out/bench_torchrun_1rank_rccl.log | cut -c1-200
+timeout 300 python bench.py --global-batch 8 --steps 2 --warmup 1 --cpu-sample 0 --no-floor > gpurun_out/bench_global_batch8_1gpu.log 2>/dev/null; tail -1 gpurun_out/bench_global_batch8_1gpu.log | cut -c1-200
+fi
