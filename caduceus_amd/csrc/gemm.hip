@@ -22,12 +22,22 @@ namespace {
 
 #define GP_WAVES 8
 
+// K = 512 (d_model 512, configs[4]) tuning knobs: W rows per wave / tokens per block / register double-buffering of the A fragments
+#ifndef GP_MB16
+#define GP_MB16 2
+#endif
+#ifndef GP_NT16
+#define GP_NT16 32
+#endif
+#ifndef GP_XFB16
+#define GP_XFB16 1
+#endif
 template <int KS>
 struct GpCfg {
-    static constexpr int MB = KS >= 16 ? 2 : 4;      // 16-row blocks of W per wave: MB * KS * 4 <= 128 VGPRs
+    static constexpr int MB = KS >= 16 ? GP_MB16 : 4;  // 16-row blocks of W per wave: MB * KS * 4 <= 128 VGPRs
     static constexpr int MW = 16 * MB;               // output channels per wave
     static constexpr int MWG = MW * GP_WAVES;        // ... per workgroup
-    static constexpr int NT = KS >= 16 ? 32 : 64;    // tokens per block (two blocks + the staging tiles fit in 160 KB)
+    static constexpr int NT = KS >= 16 ? GP_NT16 : 64;  // tokens per block (two blocks + the staging tiles fit in 160 KB)
     static constexpr int ROWB = KS * 64;             // bytes per token row (K bf16)
     static constexpr int PPR = KS * 4;               // 16-byte pieces per token row
     static constexpr int SW = (PPR < 16 ? PPR : 16) - 1;  // swizzle mask: piece ^= token & SW
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_arg
         // A fragments of sub-block q: token t = 16 q + jl, k = 32 ks + 8 g .. + 7  ->  logical piece 4 ks + g, swizzled with the token.
         // Double buffered in registers where they fit (KS <= 8): the reads of sub-block q + 1 are issued before the MFMAs of
         // sub-block q, so that the matrix cores do not idle for an LDS round trip four times per block.
-        constexpr int XFB = KS <= 8 ? 2 : 1;
+        constexpr int XFB = KS <= 8 ? 2 : GP_XFB16;
         u32x4 xfb[XFB][KS];
         auto load_frags = [&](int q, u32x4* dst) {
             const int t = q * 16 + jl;
