@@ -560,17 +560,10 @@ def lm_head(hidden: torch.Tensor, weight: torch.Tensor, comp: Optional[torch.Ten
 # ------------------------------------------------------------------------------------------------------------------
 # dense projections on the matrix cores (raw ops, no autograd: caduceus_amd/mixer.py schedules their gradients by hand)
 # ------------------------------------------------------------------------------------------------------------------
-# K = 512 (d_model 512, BASELINE configs[4]): the W-stationary kernel holds 32 rows of W per wave (128 VGPRs), so M = 2048 takes eight
-# row groups that each pull the whole X stream through LDS -- measured on the MI355X (tools/proj512_bench.py, profiles/r04_proj_d512.txt):
-# in_proj 1.76-1.80 ms own vs 1.47 ms hipBLASLt, d(y) 0.84-0.94 vs 0.70 ms (FETCH_SIZE 550 MB: X does come from L2, the kernel is bound by
-# its per-CU LDS-DMA ingest).  The library is used there; CADUCEUS_AMD_OWN_PROJ_K512=1 selects the own kernel (A/B, tests).
-_OWN_PROJ_K512 = os.environ.get("CADUCEUS_AMD_OWN_PROJ_K512", "0") == "1"
-
-
 def proj_supported(t: torch.Tensor, K: int) -> bool:
-    """The MFMA projection kernels take bf16 operands with a supported reduction length (and are the faster choice there)."""
-    if int(K) >= 512 and not _OWN_PROJ_K512:
-        return False
+    """The MFMA projection kernels take bf16 operands with a supported reduction length.  (K = 512, d_model 512: stand-alone and cold the
+    library GEMM is 18-25 % faster than the W-stationary kernel, inside the training step it is not -- 558.9 vs 555.9 ms per step;
+    profiles/r04_proj_d512.txt.  The own kernel stays.)"""
     return t.dtype == torch.bfloat16 and bool(L.get_lib().cad_proj_supported(int(K)))
 
 
