@@ -268,7 +268,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         dzv[i] = dy[i] * ys * (1.f + zz[i] * (1.f - sg));
                         dy[i] *= zz[i] * sg;
                     }
-                    if (act && !(SC_WHATIF & 2048)) sc_store<T, SC_S, VEC>(dz_row, p0, L, rev, dzv);
+                    if (act && !(SC_WHATIF & 2048))
+                        sc_by_dir(rev, [&](auto rtag) { sc_store_d<T, SC_S, VEC, decltype(rtag)::value != 0>(dz_row, p0, L, dzv); });
                 } else {
 #pragma unroll
                     for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
@@ -307,8 +308,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         // loop the compiler if-converts it and evaluates its transcendentals in every pair-step).
         auto chunk_epilogue = [&]() {
             float uu[SC_S], dl[SC_S], du[SC_S];
-            sc_unpack<T, SC_S>(u_raw, rev, uu);
-            sc_unpack<T, SC_S>(d_raw, rev, dl);
+            sc_by_dir(rev, [&](auto rtag) {
+                sc_unpack_d<T, SC_S, decltype(rtag)::value != 0>(u_raw, uu);
+                sc_unpack_d<T, SC_S, decltype(rtag)::value != 0>(d_raw, dl);
+            });
             float sgv[SC_S];
             if (is_dt) {  // wave-uniform
 #pragma unroll
@@ -330,8 +333,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 dbacc += ddt[i];
             }
             if (act && !(SC_WHATIF & 2048)) {
-                sc_store<T, SC_S, VEC>(du_row, p0, L, rev, du);
-                sc_store<T, SC_S, VEC>(dd_row, p0, L, rev, ddt);
+                sc_by_dir(rev, [&](auto rtag) {
+                    sc_store_d<T, SC_S, VEC, decltype(rtag)::value != 0>(du_row, p0, L, du);
+                    sc_store_d<T, SC_S, VEC, decltype(rtag)::value != 0>(dd_row, p0, L, ddt);
+                });
             }
         };
         SC_TIME(1);  // chunk prologue: unpack, gate, softplus

@@ -496,6 +496,59 @@ template <int V>
 struct DirTagC {
     static constexpr int value = V;
 };
+template <typename T, int S, bool REV>
+__device__ __forceinline__ void sc_unpack_d(const ScVec<T, S>& raw, float* out) {
+    if constexpr (sizeof(T) == 2 && S % 2 == 0) {
+        constexpr int NW = S / 2;
+#ifdef CAD_EMU
+        struct W { uint32_t w[NW]; };
+        const W ww = __builtin_bit_cast(W, raw);
+        const uint32_t* w = ww.w;
+#else
+        typedef uint32_t uw __attribute__((ext_vector_type(NW)));
+        const uw w = __builtin_bit_cast(uw, raw);
+#endif
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const uint32_t x = w[REV ? NW - 1 - q : q];
+            out[2 * q] = cad_bits2f(REV ? (x & 0xFFFF0000u) : (x << 16));
+            out[2 * q + 1] = cad_bits2f(REV ? (x << 16) : (x & 0xFFFF0000u));
+        }
+    } else {
+        sc_unpack<T, S>(raw, REV ? 1 : 0, out);
+    }
+}
+template <typename T, int S, bool VEC, bool REV>
+__device__ __forceinline__ void sc_store_d(T* row, int64_t p0, int64_t L, const float* v) {
+    if constexpr (VEC && sizeof(T) == 2 && (S == 8 || S == 16)) {
+        if (p0 < L) {
+            const int64_t l0 = REV ? (L - p0 - S) : p0;
+            constexpr int NW = S / 2;
+#pragma unroll
+            for (int q = 0; q < NW; q += 4) {
+                u32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int k = q + t;
+                    o[t] = REV ? cad_pack_bf16x2(v[S - 1 - 2 * k], v[S - 2 - 2 * k]) : cad_pack_bf16x2(v[2 * k], v[2 * k + 1]);
+                }
+                *(u32x4*)(row + l0 + 2 * q) = o;
+            }
+        }
+    } else {
+        sc_store<T, S, VEC>(row, p0, L, REV ? 1 : 0, v);
+    }
+}
+template <typename F>
+__device__ __forceinline__ void sc_by_dir(int rev, F&& f) {
+    if (cad_uniform(rev)) {
+        f(DirTagC<1>{});
+        
+    } else {
+        f(DirTagC<0>{});
+        
+    }
+}
 // ---- B/C tile staging: global -> registers (prefetch) -> LDS ----------------------------------------------------------
 // Threads 0..255 of the workgroup stage; thread t owns tensor (t >> 7) (0 = B, 1 = C) and the SV = S/2 logical
 // positions base + SV * (t & 127) .. of BOTH states of the pair.  Tile layout in LDS: [lane j][item i][state 0/1] fp32

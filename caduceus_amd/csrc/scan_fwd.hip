@@ -166,8 +166,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             sc_load_raw<T, SC_S, VEC>(d_row, p0, L, rev, d_raw);
         }
 #endif
-        sc_unpack<T, SC_S>(u_raw, rev, du);
-        sc_unpack<T, SC_S>(d_raw, rev, dt);
+        sc_by_dir(rev, [&](auto rtag) {  // (one scalar branch per chunk instead of a select + rotate per dword)
+            sc_unpack_d<T, SC_S, decltype(rtag)::value != 0>(u_raw, du);
+            sc_unpack_d<T, SC_S, decltype(rtag)::value != 0>(d_raw, dt);
+        });
 #ifdef SC_FWD_PREFETCH
         if (z_row) sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
         if (c + 1 < nchunks) {
@@ -281,11 +283,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             else
                 sc_load_raw<T, SC_S, VEC>(z_row, p0, L, rev, z_raw);
 #endif
-            sc_unpack<T, SC_S>(z_raw, rev, zz);
+            sc_by_dir(rev, [&](auto rtag) { sc_unpack_d<T, SC_S, decltype(rtag)::value != 0>(z_raw, zz); });
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) y[i] *= (SC_WHATIF & 1024) ? zz[i] : zz[i] * cad_sigmoid(zz[i]);
         }
-        if (act && !(SC_WHATIF & 2048)) sc_store<T, SC_S, VEC>(o_row, p0, L, rev, y);
+        if (act && !(SC_WHATIF & 2048))
+            sc_by_dir(rev, [&](auto rtag) { sc_store_d<T, SC_S, VEC, decltype(rtag)::value != 0>(o_row, p0, L, y); });
     }
     if (a.hT && act && lane < NP) {
         float* hp = a.hT + ((int64_t)e * SB + sb) * N + 2 * lane;
