@@ -61,6 +61,11 @@ class ProjTmArgs(C.Structure):
                 ("ldo", _i64)]
 
 
+class GemmStreamArgs(C.Structure):
+    _fields_ = [("A", _p), ("B", _p), ("out", _p), ("R", _i64), ("C", _i64), ("K", _i64), ("lda", _i64), ("ldb", _i64), ("ldo", _i64),
+                ("nslices", _i), ("mode", _i)]
+
+
 class Conv1dBwdArgs(C.Structure):
     _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("dout", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
                 ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i),
@@ -151,6 +156,8 @@ SYMBOLS = {
     "cad_proj_wgrad_only_supported": (_i, [_i, _i, _i64]),
     "cad_proj_xTw": (_i, [C.POINTER(ProjTmArgs), _p]),
     "cad_proj_xTw_supported": (_i, [_i, _i, _i64]),
+    "cad_gemm_stream": (_i, [C.POINTER(GemmStreamArgs), _p]),
+    "cad_gemm_stream_supported": (_i, [_i64, _i64, _i64, _i]),
     "cad_quant_rows_fp8": (_i, [C.POINTER(QuantFp8Args), _p]),
     "cad_proj_wxT_fp8": (_i, [C.POINTER(ProjFp8Args), _p]),
     "cad_proj_fp8_supported": (_i, [_i]),

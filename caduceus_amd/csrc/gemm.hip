@@ -794,6 +794,168 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
     }
 }
 
+// ---- cad_gemm_stream: D (R x C) = A (R x K) . B (K x C), both operands streamed ------------------------------------------------------
+// A workgroup owns one 256 x 256 tile of D (8 waves as 2 x 4: a wave accumulates 128 rows x 64 columns = 32 MFMA tiles = 128 fp32
+// registers) and walks its k range in chunks of 32 through a ring of 4 LDS stages (16 KB of A rows + 16 KB of B rows per stage) filled
+// by LDS-DMA three chunks ahead; per chunk a wave reads 8 A fragments directly (row-major rows, 8 consecutive k = one 16-byte piece)
+// and 4 B fragments through the transposing read (B rows are k, columns contiguous) and issues 32 MFMAs.  Both operands cross HBM
+// once per tile row / column they belong to: the kernel is the classic tiled GEMM, written for the three shapes of the mixer
+// backward where R or C is only one or four tiles wide and everything else is the stream.
+struct GsCfg {
+    static constexpr int RT = 256, CT = 256, KC = 32, RING = 4;
+    static constexpr int AROW = KC * 2;               // 64 bytes per A tile row: four 16-byte pieces, piece index ^ gs_aswz(row)
+    static constexpr int ABUF = RT * AROW;            // 16 KB
+    static constexpr int BROW = CT * 2;               // 512 bytes per B tile row (one k), 32-byte column blocks ^ gx_swz(row)
+    static constexpr int BBUF = KC * BROW;            // 16 KB
+    static constexpr int STAGE = ABUF + BBUF;
+    static constexpr int DPW = 4;                     // DMA instructions per wave and chunk (2 of A, 2 of B)
+    static constexpr size_t LDS = (size_t)RING * STAGE;
+};
+static_assert(GP_WAVES == 8, "cad_gemm_stream: 2 x 4 waves per tile, two DMA instructions per wave, operand and chunk");
+// eight consecutive rows x one 16-byte piece (what eight lanes of a ds_read_b128 touch) fall into eight different 16-byte bank groups
+__device__ __forceinline__ int gs_aswz(int row) { return (row >> 1) & 3; }
+
+__device__ __forceinline__ void gs_issue_chunk(const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int64_t k0, char* stage,
+                                               int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // A: 16 instructions of 16 rows x 4 pieces
+        const int ins = wave * 2 + i;
+        const int row = ins * 16 + (lane >> 2), pp = lane & 3;
+        const int lp = pp ^ gs_aswz(row);  // logical piece = 8 consecutive k
+        cad_glds16(A + (int64_t)row * lda + k0 + lp * 8, cad_uniform((int)(cad_lds_off(stage) + ins * 1024)));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // B: 16 instructions of 2 rows x 32 pieces
+        const int ins = wave * 2 + i;
+        const int p = ins * 64 + lane;
+        const int row = p >> 5, pp = p & 31;
+        const int lp = (((pp >> 1) ^ gx_swz(row)) << 1) | (pp & 1);  // logical piece = 8 consecutive columns
+        cad_glds16(B + (k0 + row) * ldb + lp * 8, cad_uniform((int)(cad_lds_off(stage + GsCfg::ABUF) + ins * 1024)));
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_stream_args a) {
+    typedef GsCfg C;
+    CAD_DYN_SMEM(char, smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = cad_uniform(threadIdx.x >> 6);
+    const int g = lane >> 4, jl = lane & 15;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int64_t nrt = a.R / C::RT, nct = a.C / C::CT;
+    const int64_t kper = a.K / a.nslices;            // k range of one slice
+    const int nk = (int)(kper / C::KC);              // chunks per work item
+    const int64_t nitems = nrt * nct * a.nslices;
+    const int64_t i0 = blockIdx.x, istep = gridDim.x;
+    if (i0 >= nitems) return;
+    const int64_t nmine = (nitems - i0 + istep - 1) / istep;
+    const int64_t total = nmine * nk;
+    // work item -> (slice, column tile, row tile), row tiles fastest: neighbouring workgroups share the B rows of a slice
+    auto decode = [&](int64_t item, int64_t& rt, int64_t& ct, int64_t& sl) {
+        rt = item % nrt;
+        const int64_t q = item / nrt;
+        ct = q % nct;
+        sl = q / nct;
+    };
+    // issue cursor
+    int ich = 0, islot = 0;
+    int64_t iitem = i0;
+    const bf16_t *iA = nullptr, *iB = nullptr;
+    auto seek = [&]() {
+        int64_t rt, ct, sl;
+        decode(iitem, rt, ct, sl);
+        iA = (const bf16_t*)a.A + rt * C::RT * a.lda + sl * kper;
+        iB = (const bf16_t*)a.B + sl * kper * a.ldb + ct * C::CT;
+    };
+    seek();
+    auto issue_next = [&]() {
+        gs_issue_chunk(iA, a.lda, iB, a.ldb, (int64_t)ich * C::KC, smem + islot * C::STAGE, wave, lane);
+        islot = (islot + 1) & (C::RING - 1);
+        if (++ich == nk) {
+            ich = 0;
+            iitem += istep;
+            if (iitem < nitems) seek();
+        }
+    };
+    for (int64_t it = 0; it < C::RING - 1; ++it)
+        if (it < total) issue_next();
+    constexpr int INFL = (C::RING - 2) * C::DPW;     // DMA instructions of the two later chunks that may stay in flight at a wait
+    constexpr int NST = MODE == CAD_GEMM_OUT_T_BF16 ? 32 : 128;  // output stores per wave and item
+    static_assert(INFL + 32 <= 63, "vmcnt is a 6-bit counter");
+    // lane-constant fragment addresses inside a stage
+    const int a_off = (wm * 128 + jl) * C::AROW + ((g ^ gs_aswz(jl)) * 16);       // + i * 16 * AROW  (gs_aswz(row) = gs_aswz(jl))
+    const int br0 = g * 8 + (jl >> 2);                                             // source k row of the first 4 x 16 block
+    const int b_off0 = C::ABUF + br0 * C::BROW + wn * 128 + (jl & 3) * 8;          // + ((j ^ swz) * 32)
+    const int b_off1 = b_off0 + 4 * C::BROW;
+    const int bs0 = gx_swz(br0), bs1 = gx_swz(br0 + 4);
+    f32x4 acc[8][4];
+    int slot = 0;
+    int64_t item = i0;
+    int since_store = C::RING;                       // iterations since the last store burst (see proj_xTw_kernel)
+    for (int64_t bi = 0; bi < nmine; ++bi, item += istep) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nk; ++ch) {
+            const int64_t it = bi * nk + ch;
+#ifndef CAD_EMU
+            if (it + C::RING - 2 >= total || since_store < 0 || (MODE == CAD_GEMM_PARTIALS && since_store < C::RING - 1))
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (MODE == CAD_GEMM_OUT_T_BF16 && since_store < C::RING - 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL + 32) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
+#endif
+            ++since_store;
+            __syncthreads();  // every wave's share of chunk `it` is visible; the stage consumed LAST iteration is free again
+            if (it + C::RING - 1 < total) issue_next();
+            const char* st = smem + slot * C::STAGE;
+            slot = (slot + 1) & (C::RING - 1);
+            u32x4 bfr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x2 lo = cad_lds_read_tr16(st + b_off0 + ((j ^ bs0) * 32));
+                const u32x2 hi = cad_lds_read_tr16(st + b_off1 + ((j ^ bs1) * 32));
+                bfr[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32x4 af = *(const u32x4*)(st + a_off + i * 16 * C::AROW);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = cad_mfma_16x16x32_bf16(af, bfr[j], acc[i][j]);
+            }
+        }
+        int64_t rt, ct, sl;
+        decode(item, rt, ct, sl);
+        // lane (g, jl) of tile (i, j): column ct * 256 + wn * 64 + 16 j + jl, rows rt * 256 + wm * 128 + 16 i + 4 g .. + 3
+        const int64_t col = ct * C::CT + wn * 64 + jl;
+        const int64_t row = rt * C::RT + wm * 128 + 4 * g;
+        if constexpr (MODE == CAD_GEMM_PARTIALS) {
+            float* dst = (float*)a.out + ((int64_t)sl * a.R + row) * a.C + col;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(int64_t)(16 * i + r) * a.C + 16 * j] = acc[i][j][r];
+        } else {
+            bf16_t* dst = (bf16_t*)a.out + col * a.ldo + row;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u32x2 pk;
+                    pk[0] = cad_pack_bf16x2_safe(acc[i][j][0], acc[i][j][1]);
+                    pk[1] = cad_pack_bf16x2_safe(acc[i][j][2], acc[i][j][3]);
+                    *(u32x2*)(dst + (int64_t)(16 * j) * a.ldo + 16 * i) = pk;
+                }
+        }
+        since_store = nk >= C::RING - 1 ? 0 : -C::RING;  // (items shorter than the ring: the next waits drain everything)
+    }
+    (void)NST;
+}
+
 }  // namespace
 
 // more than 64 KB of dynamic LDS has to be requested per kernel: the largest size asked for so far is remembered per
@@ -995,4 +1157,31 @@ extern "C" int cad_proj_xTw(const cad_proj_tm_args* a, void* stream) {
     CadProfScope prof(8, stream);
     if (a->M == 256) return a->K == 512 ? launch_xTw<2, 16>(a, stream) : launch_xTw<2, 8>(a, stream);
     return a->K == 512 ? launch_xTw<1, 16>(a, stream) : launch_xTw<1, 8>(a, stream);
+}
+
+// ---- cad_gemm_stream ----------------------------------------------------------------------------------------------------------------
+extern "C" int cad_gemm_stream_supported(int64_t R, int64_t C, int64_t K, int nslices) {
+    return R >= GsCfg::RT && (R % GsCfg::RT) == 0 && C >= GsCfg::CT && (C % GsCfg::CT) == 0 && nslices >= 1 && K > 0 &&
+           (K % nslices) == 0 && ((K / nslices) % GsCfg::KC) == 0;
+}
+
+extern "C" int cad_gemm_stream(const cad_gemm_stream_args* a, void* stream) {
+    CAD_CHECK_ARG(a && a->A && a->B && a->out && (a->mode == CAD_GEMM_PARTIALS || a->mode == CAD_GEMM_OUT_T_BF16));
+    if (!cad_gemm_stream_supported(a->R, a->C, a->K, a->nslices)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG(a->lda >= a->K && a->ldb >= a->C && (a->lda % 8) == 0 && (a->ldb % 8) == 0);
+    CAD_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) % 16) == 0);
+    CAD_CHECK_ARG(a->mode == CAD_GEMM_PARTIALS || (a->nslices == 1 && a->ldo >= a->R && (a->ldo % 4) == 0 && ((uintptr_t)a->out % 8) == 0));
+    CadProfScope prof(8, stream);
+    const int64_t nitems = (a->R / GsCfg::RT) * (a->C / GsCfg::CT) * a->nslices;
+    int64_t gx = 256;  // one workgroup per CU
+    if (gx > nitems) gx = nitems;
+    dim3 grid((unsigned)gx), block(64 * GP_WAVES);
+    if (a->mode == CAD_GEMM_PARTIALS) {
+        GP_BIG_LDS((gemm_stream_kernel<CAD_GEMM_PARTIALS>), GsCfg::LDS);
+        CAD_LAUNCH((gemm_stream_kernel<CAD_GEMM_PARTIALS>), grid, block, GsCfg::LDS, stream, *a);
+    } else {
+        GP_BIG_LDS((gemm_stream_kernel<CAD_GEMM_OUT_T_BF16>), GsCfg::LDS);
+        CAD_LAUNCH((gemm_stream_kernel<CAD_GEMM_OUT_T_BF16>), grid, block, GsCfg::LDS, stream, *a);
+    }
+    return cad_after_launch();
 }

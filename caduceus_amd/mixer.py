@@ -116,6 +116,10 @@ def _own_wgrad_chunked(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
 def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
     """a (M, T) channel-major @ b (T, N) token-major -> (M, N) fp32."""
     M, T = a_cm.shape
+    if _OWN_GEMM:
+        own = ops.wgrad_cm_tm(a_cm, b_tm)
+        if own is not None:
+            return own
     n = _kchunks(T)
     if n == 1:
         return torch.mm(a_cm, b_tm).float()
@@ -136,6 +140,9 @@ _FUSED_WGRAD = os.environ.get("CADUCEUS_AMD_FUSED_WGRAD", "1") != "0"
 _OWN_DWX = os.environ.get("CADUCEUS_AMD_OWN_DWX", "1") != "0"
 # out_proj forward on the own token-major-output MFMA kernel (cad_proj_xTw); CADUCEUS_AMD_OWN_OUT_PROJ=0: hipBLASLt on [y_f ; y_r]
 _OWN_OUT_PROJ = os.environ.get("CADUCEUS_AMD_OWN_OUT_PROJ", "1") != "0"
+# d(x2d), dW_in and dW_out -- the products whose two operands both stream -- on the own tiled MFMA kernel (cad_gemm_stream: fp32
+# accumulation over ALL tokens for the weight gradients); CADUCEUS_AMD_OWN_GEMM=0: torch.mm / K-split bmm (hipBLASLt)
+_OWN_GEMM = os.environ.get("CADUCEUS_AMD_OWN_GEMM", "1") != "0"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
@@ -188,7 +195,7 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
         alog += [mf.A_log.detach().float(), mr.A_log.detach().float()]
         owners.append((mf, ps + [mf.A_log, mr.A_log], out))
     torch._foreach_copy_(dst, src)
-    trans = {kd: stacked[kd].transpose(1, 2).contiguous() for kd in ("out", "x", "dt") if kd in stacked}
+    trans = {kd: stacked[kd].transpose(1, 2).contiguous() for kd in ("out", "x", "dt", "in") if kd in stacked}
     cursor = {kd: 0 for kd in kinds}
 
     def transposed(kd, w):
@@ -199,14 +206,14 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
         return w.t().contiguous()
 
     for mf, ps, out in owners:
-        # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T], in the order the stacked buffers were filled
-        out.append([transposed(kd, out[j]) for kd, j in (("out", 1), ("x", 2), ("dt", 3), ("x", 4), ("dt", 5))])
+        # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T, W_in^T], in the order the stacked buffers were filled
+        out.append([transposed(kd, out[j]) for kd, j in (("out", 1), ("x", 2), ("dt", 3), ("x", 4), ("dt", 5), ("in", 0))])
     negA = torch._foreach_exp(alog)
     torch._foreach_neg_(negA)
     for i, (mf, ps, out) in enumerate(owners):
-        tr = out.pop()  # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T]
+        tr = out.pop()  # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T, W_in^T]
         mf._cad_step_cache = {"versions": [(id(p), p._version) for p in ps], "w": out, "A": (negA[2 * i], negA[2 * i + 1]),
-                              "wT": {"out": tr[0], "x": (tr[1], tr[3]), "dt": (tr[2], tr[4])}}
+                              "wT": {"out": tr[0], "x": (tr[1], tr[3]), "dt": (tr[2], tr[4]), "in": tr[5]}}
         if _FP8_IN_PROJ and act == torch.bfloat16 and ops.fp8_proj_supported(out[0], out[0].shape[1]):
             mf._cad_step_cache["w_in_fp8"] = ops.quant_weight_fp8(ps[0])  # from the fp32 master weight, once per step
 
@@ -438,7 +445,9 @@ class BiMambaMixerFn(torch.autograd.Function):
                       dD.to(meta[6][0])]
         if dz_r is not None:
             dxz[E:].add_(dz_r)
-        dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
+        dx2d = ops.proj_xTw_stream(wT["in"] if wT else w_in.t().contiguous(), dxz.view(2 * E, T)) if _OWN_GEMM else None
+        if dx2d is None:
+            dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
         dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
         return (dx2d, None, None, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
 

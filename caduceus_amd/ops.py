@@ -629,10 +629,61 @@ def proj_xTw(W: torch.Tensor, X: torch.Tensor, X2: Optional[torch.Tensor] = None
     T = X.shape[1]
     if out is None:
         out = torch.empty((T, M), dtype=X.dtype, device=X.device)
-    stream = L.stream_and_check(W, X, X2, out)
+    stream = L.stream_and_check(W, X, X2, out, contiguous=False)
     assert W.stride(1) == 1 and X.stride(1) == 1 and out.stride(1) == 1 and (X2 is None or (X2.stride() == X.stride() and X2.shape == X.shape))
     a = L.ProjTmArgs(L.ptr(W), L.ptr(X), L.ptr(X2), L.ptr(out), T, M, K, W.stride(0), X.stride(0), out.stride(0))
     L.check(L.get_lib().cad_proj_xTw(C.byref(a), stream), "cad_proj_xTw")
+    return out
+
+
+GEMM_PARTIALS, GEMM_OUT_T_BF16 = 0, 1
+
+
+def gemm_stream_slices(R: int, Cc: int, K: int) -> int:
+    """K slices of a weight gradient: as many as fill the GPU with one 256 x 256 tile per workgroup (cad_gemm_stream), 0 = unsupported."""
+    if R % 256 or Cc % 256 or R < 256 or Cc < 256:
+        return 0
+    n = max(1, _cu_count() // ((R // 256) * (Cc // 256)))
+    while n > 1 and (K % (32 * n) != 0):
+        n -= 1
+    return n if K % (32 * n) == 0 else 0
+
+
+def wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> Optional[torch.Tensor]:
+    """(M, N) fp32 = a (M, T) channel-major @ b (T, N) token-major, bf16 operands, fp32 accumulation over ALL tokens (cad_gemm_stream,
+    CAD_GEMM_PARTIALS: one fp32 tile per K slice, summed here): dW_in and dW_out of the mixer.  None if the shape is not served."""
+    M, T = a_cm.shape
+    N = b_tm.shape[1]
+    if a_cm.dtype != torch.bfloat16 or b_tm.dtype != torch.bfloat16 or a_cm.stride(1) != 1 or b_tm.stride(1) != 1:
+        return None
+    if a_cm.stride(0) % 8 or b_tm.stride(0) % 8 or a_cm.data_ptr() % 16 or b_tm.data_ptr() % 16:
+        return None
+    n = gemm_stream_slices(M, N, T)
+    if n == 0 or not L.get_lib().cad_gemm_stream_supported(M, N, T, n):
+        return None
+    part = torch.empty((n, M, N), dtype=torch.float32, device=a_cm.device)
+    stream = L.stream_and_check(a_cm, b_tm, part, contiguous=False)
+    a = L.GemmStreamArgs(L.ptr(a_cm), L.ptr(b_tm), L.ptr(part), M, N, T, a_cm.stride(0), b_tm.stride(0), 0, n, GEMM_PARTIALS)
+    L.check(L.get_lib().cad_gemm_stream(C.byref(a), stream), "cad_gemm_stream")
+    return part[0] if n == 1 else part.sum(0)
+
+
+def proj_xTw_stream(Wt: torch.Tensor, X: torch.Tensor) -> Optional[torch.Tensor]:
+    """out (T, M) token-major bf16 = X (K, T)^T @ Wt (M, K)^T with X channel-major and BOTH operands streamed (cad_gemm_stream,
+    CAD_GEMM_OUT_T_BF16): d(x2d) = dxz^T W_in with Wt = W_in^T (D, 2E), K = 2E too deep for resident weight fragments.  None if the
+    shape is not served."""
+    M, K = Wt.shape
+    T = X.shape[1]
+    if Wt.dtype != torch.bfloat16 or X.dtype != torch.bfloat16 or Wt.stride(1) != 1 or X.stride(1) != 1:
+        return None
+    if Wt.stride(0) % 8 or X.stride(0) % 8 or Wt.data_ptr() % 16 or X.data_ptr() % 16:
+        return None
+    if not L.get_lib().cad_gemm_stream_supported(M, T, K, 1):
+        return None
+    out = torch.empty((T, M), dtype=torch.bfloat16, device=X.device)
+    stream = L.stream_and_check(Wt, X, out, contiguous=False)
+    a = L.GemmStreamArgs(L.ptr(Wt), L.ptr(X), L.ptr(out), M, T, K, Wt.stride(0), X.stride(0), out.stride(0), 1, GEMM_OUT_T_BF16)
+    L.check(L.get_lib().cad_gemm_stream(C.byref(a), stream), "cad_gemm_stream")
     return out
 
 

@@ -356,6 +356,32 @@ int cad_proj_xTw(const cad_proj_tm_args* a, void* stream);
 int cad_proj_xTw_supported(int M, int K, int64_t T);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * cad_gemm_stream -- the dense products of the mixer's backward whose two operands BOTH stream (no operand fits a CU's registers):
+ * the in_proj input gradient d(x2d) and the two weight gradients dW_in / dW_out of mamba_ssm.Mamba as run by
+ * modeling_caduceus.py:128,130 (the backward of `xz = in_proj(hidden)` / `out = out_proj(y)`; torch.mm / K-split bmm -> hipBLASLt
+ * until round 4).  One kernel, bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16:
+ *     D (R x C) = A (R x K) . B (K x C),   A row-major [r][k] (lda elements between rows, k contiguous),
+ *                                          B row-major [k][c] (ldb elements between rows, c contiguous)
+ * mode CAD_GEMM_PARTIALS: k in [0, K) is cut into `nslices` equal slices; slice s of tile (r, c) is one workgroup and writes its fp32
+ *   tile to partials[s][R][C] (the caller sums the slices in fp32: a weight gradient over all tokens, K = T);
+ * mode CAD_GEMM_OUT_T_BF16: out (C x R) bf16 = D^T, rows ldo elements apart (token-major d(x2d): A = W_in^T (D x 2E), B = dxz
+ *   (2E x T) channel-major, C = T; nslices must be 1).
+ * R, C multiples of 256, K / nslices a multiple of 32 (cad_gemm_stream_supported); 16-byte aligned operands, lda / ldb % 8 == 0. */
+#define CAD_GEMM_PARTIALS 0
+#define CAD_GEMM_OUT_T_BF16 1
+typedef struct {
+    const void* A;
+    const void* B;
+    void* out;      /* fp32 partials (nslices, R, C) or bf16 (C, ldo) */
+    int64_t R, C, K;
+    int64_t lda, ldb, ldo;
+    int nslices;
+    int mode;
+} cad_gemm_stream_args;
+int cad_gemm_stream(const cad_gemm_stream_args* a, void* stream);
+int cad_gemm_stream_supported(int64_t R, int64_t C, int64_t K, int nslices);
+
+/* ---------------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) projections -- BASELINE configs[4] "fp8 MFMA projections": the same `in_proj` nn.Linear call of
  * mamba_ssm.Mamba.forward (modeling_caduceus.py:128,130) on v_mfma_f32_16x16x32_fp8_fp8 with fp32 accumulation.
  * cad_quant_rows_fp8:  q (T, K) e4m3 = x (T, K) / scale[t],  scale[t] = max|x[t, :]| / 448 (1 for an all-zero row), one

@@ -63,7 +63,8 @@ def test_ctypes_structs_mirror_header():
               "cad_scan_args": _lib.ScanArgs, "cad_scan_bwd_args": _lib.ScanBwdArgs,
               "cad_lm_head_args": _lib.LmHeadArgs, "cad_lm_head_bwd_args": _lib.LmHeadBwdArgs, "cad_mlm_args": _lib.MlmArgs,
               "cad_proj_args": _lib.ProjArgs, "cad_quant_fp8_args": _lib.QuantFp8Args,
-              "cad_proj_fp8_args": _lib.ProjFp8Args, "cad_proj_tm_args": _lib.ProjTmArgs, "cad_reduce_job": _lib.ReduceJob}
+              "cad_proj_fp8_args": _lib.ProjFp8Args, "cad_proj_tm_args": _lib.ProjTmArgs, "cad_reduce_job": _lib.ReduceJob,
+              "cad_gemm_stream_args": _lib.GemmStreamArgs}
     assert set(hs) == set(mirror)
     for name, cls in mirror.items():
         assert [f[0] for f in cls._fields_] == hs[name], name
@@ -84,7 +85,8 @@ def test_struct_sizes_match_compiler(tmp_path):
               "cad_scan_args": _lib.ScanArgs, "cad_scan_bwd_args": _lib.ScanBwdArgs,
               "cad_lm_head_args": _lib.LmHeadArgs, "cad_lm_head_bwd_args": _lib.LmHeadBwdArgs, "cad_mlm_args": _lib.MlmArgs,
               "cad_proj_args": _lib.ProjArgs, "cad_quant_fp8_args": _lib.QuantFp8Args,
-              "cad_proj_fp8_args": _lib.ProjFp8Args, "cad_proj_tm_args": _lib.ProjTmArgs, "cad_reduce_job": _lib.ReduceJob}
+              "cad_proj_fp8_args": _lib.ProjFp8Args, "cad_proj_tm_args": _lib.ProjTmArgs, "cad_reduce_job": _lib.ReduceJob,
+              "cad_gemm_stream_args": _lib.GemmStreamArgs}
     for n, cls in mirror.items():
         assert int(sizes[n]) == ctypes.sizeof(cls), n
 

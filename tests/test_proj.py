@@ -240,3 +240,69 @@ def test_mixer_layer_own_out_proj_matches_the_library_path(backend, monkeypatch)
         res[own] = (out.detach().float().cpu(), hn.grad.float().cpu(), mf.out_proj.weight.grad.float().cpu())
     for a, b in zip(res[True], res[False]):
         torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("M,N,T,slices", [(256, 256, 128, None), (512, 256, 32 * 12, None), (256, 512, 64, None), (1024, 256, 32 * 5, 1)])
+def test_gemm_stream_weight_gradient_partials(backend, monkeypatch, M, N, T, slices):
+    """cad_gemm_stream / CAD_GEMM_PARTIALS: (M, N) fp32 = a (M, T) channel-major @ b (T, N) token-major over ALL tokens, fp32
+    accumulation (dW_in / dW_out of the mixer), against the fp32 product of the same bf16 operands -- for several K-slice counts, on
+    operands that are views with a row pitch."""
+    name, dev = backend
+    if slices is not None:
+        monkeypatch.setattr(ops, "_cu_count", lambda: slices * (M // 256) * (N // 256))
+    a_full, b_full = _bf(M, T + 16, seed=41), _bf(T, N + 8, seed=42)
+    a, b = a_full.to(dev)[:, 8:8 + T], b_full.to(dev)[:, :N]
+    out = ops.wgrad_cm_tm(a, b)
+    assert out is not None and out.shape == (M, N) and out.dtype == torch.float32
+    ref = a_full[:, 8:8 + T].float() @ b_full[:, :N].float()
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    # shapes the kernel does not serve are refused, not mis-computed
+    assert ops.wgrad_cm_tm(a[:200], b) is None and ops.wgrad_cm_tm(a, b[:, :100]) is None
+
+
+@pytest.mark.parametrize("M,K,T", [(256, 1024, 256), (256, 512, 768), (512, 64, 256), (256, 32, 512)])
+def test_gemm_stream_token_major_input_gradient(backend, M, K, T):
+    """cad_gemm_stream / CAD_GEMM_OUT_T_BF16: out (T, M) token-major bf16 = X (K, T)^T @ Wt (M, K)^T with both operands streamed
+    (d(x2d) = dxz^T W_in, K = 2 d_inner) -- against the fp32 product and one bf16 rounding of it, several tiles per workgroup."""
+    name, dev = backend
+    Wt, X = _bf(M, K, seed=43), _bf(K, T, seed=44)
+    out = ops.proj_xTw_stream(Wt.to(dev), X.to(dev))
+    assert out is not None and out.shape == (T, M) and out.dtype == torch.bfloat16
+    ref = X.float().t() @ Wt.float().t()
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max()) / 8)
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 8)
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(5))
+    out_p = ops.proj_xTw_stream(Wt.to(dev), X[:, perm].contiguous().to(dev))
+    assert torch.equal(out.cpu()[perm], out_p.cpu())  # position independence (RC-equivariance of the t-frame)
+    assert ops.proj_xTw_stream(Wt.to(dev)[:100], X.to(dev)) is None
+
+
+def test_mixer_layer_own_streaming_gemms_match_the_library_path(backend, monkeypatch):
+    """One d_model 256 BiMamba mixer layer backward with d(x2d), dW_in and dW_out on cad_gemm_stream against the torch.mm / K-split bmm
+    (hipBLASLt) path: the input gradient within one bf16 rounding of the same fp32-accumulated product (bit-identical on the MI355X
+    at the production shape, tools/gemm_stream_bench.py), the weight gradients within the rounding of the library's bf16 partial products."""
+    from caduceus_amd import mixer
+    from caduceus_amd.mamba import Mamba
+    name, dev = backend
+    torch.manual_seed(4)
+    D, Lq = 256, 256
+    mf, mr = Mamba(D, device=dev), Mamba(D, device=dev)
+    mr.in_proj.weight = mf.in_proj.weight
+    mr.out_proj.weight = mf.out_proj.weight
+    hn0 = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    g = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    res = {}
+    for own in (True, False):
+        monkeypatch.setattr(mixer, "_OWN_GEMM", own)
+        for p in list(mf.parameters()) + list(mr.parameters()):
+            p.grad = None
+        hn = hn0.clone().requires_grad_(True)
+        out = mixer.bimamba_mixer(hn, mf, mr, 1)
+        out.backward(g)
+        res[own] = (hn.grad.float().cpu(), mf.in_proj.weight.grad.float().cpu(), mf.out_proj.weight.grad.float().cpu())
+    assert ops.proj_xTw_stream(mf.in_proj.weight.detach().to(torch.bfloat16).t().contiguous(),
+                               torch.zeros(4 * D, 2 * Lq, dtype=torch.bfloat16, device=dev)) is not None
+    assert ops.wgrad_cm_tm(torch.zeros(4 * D, 2 * Lq, dtype=torch.bfloat16, device=dev),
+                           torch.zeros(2 * Lq, D, dtype=torch.bfloat16, device=dev)) is not None
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).norm() / b.norm()) < 5e-3
