@@ -1,0 +1,92 @@
+// How fast does a (M x T) bf16 channel-major matrix stream from HBM when a workgroup fetches ROWS rows x PB contiguous bytes per chunk
+// by LDS-DMA (the access pattern of a tiled GEMM's strided operand)?  Standalone:
+//   hipcc --offload-arch=gfx950 -O3 -o rowstream rowstream.hip && ./rowstream
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+__device__ __forceinline__ void glds16(const void* g, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+}
+
+// chunk = ROWS x PB bytes; 8 waves; IPW = DMA instructions per wave and chunk; ring of 4 chunks, 2 in flight behind the awaited one
+template <int ROWS, int PB>
+__global__ __launch_bounds__(512, 1) void rowstream(const uint16_t* A, long long ld, long long T, int nrt, long long tok_per_slice, unsigned* sink) {
+    extern __shared__ char smem[];
+    constexpr int CH = ROWS * PB, IPW = CH / 1024 / 8, LPR = PB / 16;  // lanes per row
+    static_assert(IPW >= 1, "chunk too small");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rt = blockIdx.x % nrt;
+    const long long sl = blockIdx.x / nrt;
+    const uint16_t* base = A + (long long)rt * ROWS * ld + sl * tok_per_slice;
+    const int nch = (int)(tok_per_slice / (PB / 2));
+    auto issue = [&](int c, int slot) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int ins = wave * IPW + i;
+            const int p = ins * 64 + lane;
+            const int row = p / LPR, pp = p % LPR;
+            glds16(base + (long long)row * ld + (long long)c * (PB / 2) + pp * 8,
+                   __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + slot * CH) + ins * 1024));
+        }
+    };
+    for (int c = 0; c < 3 && c < nch; ++c) issue(c, c);
+    unsigned acc = 0;
+    for (int c = 0; c < nch; ++c) {
+        if (c + 2 >= nch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * IPW) : "memory");
+        __syncthreads();
+        if (c + 3 < nch) issue(c + 3, (c + 3) & 3);
+        acc += *(const unsigned*)(smem + (c & 3) * CH + threadIdx.x * 4);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int ROWS, int PB>
+static void run(const uint16_t* A, long long M, long long T, long long ld, unsigned* sink, void* flush, size_t flush_bytes) {
+    const int nrt = (int)(M / ROWS);
+    int nsl = 256 / nrt;
+    if (nsl < 1) nsl = 1;
+    const long long tps = T / nsl;
+    const size_t lds = 4 * (size_t)ROWS * PB;
+    hipFuncSetAttribute((const void*)rowstream<ROWS, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f, sum = 0;
+    for (int rep = 0; rep < 7; ++rep) {
+        hipMemsetAsync(flush, rep, flush_bytes, 0);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((rowstream<ROWS, PB>), dim3(nrt * nsl), dim3(512), lds, 0, A, ld, T, nrt, tps, sink);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0) { sum += ms; if (ms < best) best = ms; }
+    }
+    printf("rows %4d x %4d B  (chunk %2d KB, %3d workgroups, ld = T + %lld): median-ish %.4f ms  best %.4f ms = %.2f TB/s\n", ROWS, PB, ROWS * PB / 1024,
+           nrt * nsl, ld - T, sum / 6, best, (double)M * T * 2 / best / 1e9);
+}
+
+int main() {
+    const long long M = 1024, T = 262144;
+    unsigned* sink; hipMalloc(&sink, 4);
+    void* flush; const size_t fb = 600u << 20; hipMalloc(&flush, fb);
+    for (long long pad : {0LL, 64LL, 192LL}) {
+        const long long ld = T + pad;
+        uint16_t* A; hipMalloc(&A, (size_t)M * ld * 2);
+        hipMemset(A, 1, (size_t)M * ld * 2);
+        run<256, 64>(A, M, T, ld, sink, flush, fb);
+        run<256, 128>(A, M, T, ld, sink, flush, fb);
+        run<128, 128>(A, M, T, ld, sink, flush, fb);
+        run<128, 256>(A, M, T, ld, sink, flush, fb);
+        run<64, 256>(A, M, T, ld, sink, flush, fb);
+        run<64, 512>(A, M, T, ld, sink, flush, fb);
+        run<32, 512>(A, M, T, ld, sink, flush, fb);
+        run<32, 1024>(A, M, T, ld, sink, flush, fb);
+        run<16, 1024>(A, M, T, ld, sink, flush, fb);
+        hipFree(A);
+    }
+    return 0;
+}
