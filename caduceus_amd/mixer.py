@@ -116,7 +116,7 @@ def _own_wgrad_chunked(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
 def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
     """a (M, T) channel-major @ b (T, N) token-major -> (M, N) fp32."""
     M, T = a_cm.shape
-    if _OWN_GEMM:
+    if _OWN_GEMM and b_tm.shape[1] <= 256:  # (one column tile: at d_model 512 the library's K-split is 12 % faster, profiles/r04_gemm_stream.txt)
         own = ops.wgrad_cm_tm(a_cm, b_tm)
         if own is not None:
             return own
@@ -445,7 +445,9 @@ class BiMambaMixerFn(torch.autograd.Function):
                       dD.to(meta[6][0])]
         if dz_r is not None:
             dxz[E:].add_(dz_r)
-        dx2d = ops.proj_xTw_stream(wT["in"] if wT else w_in.t().contiguous(), dxz.view(2 * E, T)) if _OWN_GEMM else None
+        # (d_model 256: one 256-row tile, dxz read once; the configs[4] step with all three products on the own kernel measured 570.7 ms
+        # against 555.9 ms with the library: d_model 512 stays there)
+        dx2d = ops.proj_xTw_stream(wT["in"] if wT else w_in.t().contiguous(), dxz.view(2 * E, T)) if _OWN_GEMM and Dm <= 256 else None
         if dx2d is None:
             dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
         dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
