@@ -4,7 +4,9 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_final.log 2>&1; grep -n "passed\|failed" gpurun_out/pytest_gpu_final.log | tail -2; grep -n "^FAILED\|^ERROR" gpurun_out/pytest_gpu_final.log | head
+# ("quick": the kernel-level files only -- the whole suite takes 9 GPU-minutes, the driver runs it again at round end)
+if [ "$1" = quick ]; then SUITE="tests/test_kernels.py tests/test_proj.py tests/test_fp8.py tests/test_equivariance.py"; else SUITE=tests; fi
+timeout 1800 python -m pytest $SUITE -m gpu -q > gpurun_out/pytest_gpu_final.log 2>&1; grep -n "passed\|failed" gpurun_out/pytest_gpu_final.log | tail -2; grep -n "^FAILED\|^ERROR" gpurun_out/pytest_gpu_final.log | head
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 rm -rf gpurun_out/prof; timeout 900 bash tools/prof_scan.sh > gpurun_out/prof_scan.log 2>&1
 python tools/make_scan_pmc_json.py gpurun_out/prof gpurun_out/scan_pmc.json 2>&1 | tail -1 | cut -c1-400
