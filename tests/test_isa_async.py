@@ -134,3 +134,27 @@ def test_streaming_outputs_leave_with_nontemporal_stores(tmp_path, src, kernels)
         for n in inst:
             nt = len(re.findall(r"global_store_dword\w*\s.*\bnt\b", bodies[n]))
             assert nt > 0, f"{n}: no nontemporal store"
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gemm_stream_counted_waits_match_the_issued_operations(tmp_path):
+    """cad_gemm_stream waits with `s_waitcnt vmcnt(N)` where N counts what the wave issued BEHIND the awaited chunk: the LDS-DMA
+    instructions of the two later chunks (4 per wave and chunk) and -- in the token-major output mode -- the 32 output stores of a
+    finished tile (vmcnt retires in issue order).  Held on the ISA: the immediates are 8 and 8 + 32, a wave issues its DMA in groups of
+    four, and the store burst of a tile is exactly 32 instructions (a 33rd would let a wait return before its chunk has landed)."""
+    out = tmp_path / "gemm.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-S", "--cuda-device-only", "-o",
+                           str(out), os.path.join(ROOT, "caduceus_amd", "csrc", "gemm.hip")], stderr=subprocess.DEVNULL)
+    bodies = {n: b for n, b in _kernel_bodies(open(out).read()).items() if "gemm_stream_kernel" in n}
+    assert len(bodies) == 2
+    for name, body in bodies.items():
+        waits = {int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)}
+        dma = len(re.findall(r"global_load_lds_dwordx4", body))
+        assert dma > 0 and dma % 4 == 0, (name, dma)
+        assert len(re.findall(r"v_mfma_f32_16x16x32_bf16", body)) == 32, name  # one k step of a 128 x 64 wave tile
+        if "ILi1E" in name:  # CAD_GEMM_OUT_T_BF16
+            assert waits == {0, 8, 40}, (name, waits)
+            assert len(re.findall(r"global_store_dwordx2", body)) == 32 and not re.findall(r"global_store_dword\b", body), name
+        else:                # CAD_GEMM_PARTIALS: the fp32 tile leaves once, behind the last chunk
+            assert waits == {0, 8}, (name, waits)
+            assert len(re.findall(r"global_store_dword\b", body)) == 128, name
