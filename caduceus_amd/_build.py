@@ -33,7 +33,7 @@ def source_hash(defines=()) -> str:
     return h.hexdigest()[:12]
 
 
-SCAN_SOURCES = ("scan_fwd.hip", "scan_bwd.hip", "scan_common.h", "cad_common.h")
+SCAN_SOURCES = ("scan_fwd.hip", "scan_bwd.hip", "scan_common.h", "scan_prims_gfx950.h", "cad_common.h", "cad_prims_gfx950.h", "cad_types.h")
 
 
 def scan_source_hash() -> str:

@@ -16,14 +16,10 @@
 
 template <int FAMILY, typename V>
 __device__ __forceinline__ void cad_store_stream(V* p, V v) {
-#ifdef CAD_EMU
-    *p = v;
-#else
     if constexpr ((CAD_NT_MASK >> FAMILY) & 1)
-        __builtin_nontemporal_store(v, p);
+        cad_nt_store(p, v);
     else
         *p = v;
-#endif
 }
 // N fp32 values -> N contiguous elements of T at dst (as cad_cvt_store), streamed
 template <int FAMILY, typename T, int N>

@@ -205,9 +205,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv1d_fwd_kernel(ConvFwdSets sets
             // the stores stay BEHIND the wait for this tile's load: the scheduler would hoist them in front of it (and the wait
             // for a load is a vmcnt(0) that then waits for the stores just issued).  The asm consumes one converted value, so the
             // wait is placed before it, and orders the memory operations around it.
-#ifndef CAD_EMU
-            asm volatile("" : "+v"(own[0]) : : "memory");
-#endif
+            cad_order_point(own[0]);
             if (it > 0 && useful) {
 #pragma unroll
                 for (int s = 0; s < NSETS; ++s) store_raw<T>((T*)sets.s[s].out + row_prev * L, l0_prev, L, po[s]);

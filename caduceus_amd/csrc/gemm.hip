@@ -68,11 +68,7 @@ __device__ __forceinline__ void gp_issue_block(const bf16_t* X, int64_t ldx, int
     }
 }
 
-__device__ __forceinline__ void gp_wait_dma() {
-#ifndef CAD_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
+__device__ __forceinline__ void gp_wait_dma() { cad_wait_vmcnt<0>(); }
 
 template <int KS>
 __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_wxT_kernel(cad_proj_args a) {
@@ -440,12 +436,10 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
     for (int64_t it = 0; it < total; ++it) {
         // chunk `it` has landed: of this wave's DMA, at most the two later chunks (4 instructions) may still be in flight --
         // fewer near the end of the stream, where everything is waited for
-#ifndef CAD_EMU
         if (it + C::RING - 2 < total)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            cad_wait_vmcnt<4>();
         else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+            cad_wait_vmcnt<0>();
         __syncthreads();  // every wave's share of the chunk is visible; the tile consumed LAST iteration is free again
         if (it + C::RING - 1 < total) issue_next();
         if (ch == 0) {
@@ -561,12 +555,10 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_wgrad_kernel(ca
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int64_t it = bi * NCH + ch;
-#ifndef CAD_EMU
             if (it + C::RING - 2 < total)
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (a Y tile issued behind the chunks only makes this wait stricter)
+                cad_wait_vmcnt<4>();  // (a Y tile issued behind the chunks only makes this wait stricter)
             else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+                cad_wait_vmcnt<0>();
             __syncthreads();
             if (it + C::RING - 1 < total) issue(it + C::RING - 1);
             if (ch == 0 && bi + 1 < nmine) issue_y(bi + 1);  // a whole block ahead of its use
@@ -736,14 +728,12 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
                 // issue order on gfx9-class hardware, loads, LDS-DMA and stores alike): the two later chunks (4 instructions) and -- for the
                 // three waits that follow a block's output stores -- those NST stores.  A plain vmcnt(4) there drained the stores AND the
                 // freshly issued prefetch once per block (200 instead of ~140 us per launch, profiles/r04_out_proj.txt).
-#ifndef CAD_EMU
                 if (it + XR - 2 >= total || since_store < 0)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    cad_wait_vmcnt<0>();
                 else if (since_store < XR - 1)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL + NST) : "memory");
+                    cad_wait_vmcnt<INFL + NST>();
                 else
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
-#endif
+                    cad_wait_vmcnt<INFL>();
                 ++since_store;
                 __syncthreads();  // every wave's share of the chunk is visible; the tile consumed LAST iteration is free again
                 if (it + XR - 1 < total) issue_next();
@@ -899,14 +889,12 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int ch = 0; ch < nk; ++ch) {
             const int64_t it = bi * nk + ch;
-#ifndef CAD_EMU
             if (it + C::RING - 2 >= total || since_store < 0 || (MODE == CAD_GEMM_PARTIALS && since_store < C::RING - 1))
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                cad_wait_vmcnt<0>();
             else if (MODE == CAD_GEMM_OUT_T_BF16 && since_store < C::RING - 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL + 32) : "memory");
+                cad_wait_vmcnt<INFL + 32>();
             else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
-#endif
+                cad_wait_vmcnt<INFL>();
             ++since_store;
             __syncthreads();  // every wave's share of chunk `it` is visible; the stage consumed LAST iteration is free again
             if (it + C::RING - 1 < total) issue_next();
@@ -958,25 +946,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_
 
 }  // namespace
 
-// more than 64 KB of dynamic LDS has to be requested per kernel: the largest size asked for so far is remembered per
-// call site (= per kernel instantiation) AND per device, so a later launch with a larger K (or on another GPU of the same
-// process) raises the attribute again
-#if defined(CAD_EMU)
-#define GP_BIG_LDS(kern, bytes) (void)0
-#else
-#define GP_BIG_LDS(kern, bytes)                                                                                      \
-    do {                                                                                                             \
-        static size_t cur[CAD_MAX_DEVICES] = {0};                                                                    \
-        int dev_ = 0;                                                                                                \
-        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= CAD_MAX_DEVICES) return CAD_ERR_LAUNCH;         \
-        if ((size_t)(bytes) > 65536 && (size_t)(bytes) > cur[dev_]) {                                                \
-            if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != \
-                hipSuccess)                                                                                          \
-                return CAD_ERR_LAUNCH;                                                                               \
-            cur[dev_] = (size_t)(bytes);                                                                             \
-        }                                                                                                            \
-    } while (0)
-#endif
+#define GP_BIG_LDS(kern, bytes) CAD_BIG_LDS(kern, bytes)  // (cad_prims_gfx950.h)
 
 extern "C" int cad_proj_supported(int K) { return K == 32 || K == 64 || K == 128 || K == 256 || K == 512; }
 

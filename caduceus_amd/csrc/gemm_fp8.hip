@@ -15,39 +15,6 @@ namespace {
 
 #define GF_WAVES 8
 
-// v_mfma_f32_16x16x32_fp8_fp8: D (16 x 16 fp32) = A (16 x 32 e4m3) . B (32 x 16 e4m3) + C.  Lane l, g = l >> 4:
-// A: row l & 15, elements k = 8g .. 8g+7 (byte t of the 64-bit operand = element 8g + t); B: column l & 15, same k; C / D as
-// the bf16 form (column l & 15, rows 4g + r).
-#ifdef CAD_EMU
-__device__ __forceinline__ f32x4 cad_mfma_16x16x32_fp8(u32x2 a, u32x2 b, f32x4 c) {
-    const int lane = emu::lane_id();
-    const int col = lane & 15, rg = lane >> 4;
-    float bk[32], ak[4][32];
-    const uint64_t mine_a = (uint64_t)a[0] | ((uint64_t)a[1] << 32), mine_b = (uint64_t)b[0] | ((uint64_t)b[1] << 32);
-    for (int g = 0; g < 4; ++g) {
-        const uint64_t vb = emu_exchange(mine_b, g * 16 + col);
-        for (int t = 0; t < 8; ++t) bk[8 * g + t] = cad_e4m3_to_f32((uint8_t)(vb >> (8 * t)));
-        for (int r = 0; r < 4; ++r) {
-            const uint64_t va = emu_exchange(mine_a, g * 16 + 4 * rg + r);
-            for (int t = 0; t < 8; ++t) ak[r][8 * g + t] = cad_e4m3_to_f32((uint8_t)(va >> (8 * t)));
-        }
-    }
-    f32x4 d = c;
-    for (int r = 0; r < 4; ++r) {
-        float s = c[r];
-        for (int k = 0; k < 32; ++k) s += ak[r][k] * bk[k];
-        d[r] = s;
-    }
-    return d;
-}
-#else
-__device__ __forceinline__ f32x4 cad_mfma_16x16x32_fp8(u32x2 a, u32x2 b, f32x4 c) {
-    typedef float f32x4_hw __attribute__((ext_vector_type(4)));
-    const f32x4_hw r = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b),
-                                                                  __builtin_bit_cast(f32x4_hw, c), 0, 0, 0);
-    return __builtin_bit_cast(f32x4, r);
-}
-#endif
 
 // ---- per-token quantisation: one wave per row --------------------------------------------------------------------------
 template <typename T, int EPL /* elements per lane: K = 64 * EPL */>
@@ -105,11 +72,7 @@ __device__ __forceinline__ void gf_issue_block(const uint8_t* X, int64_t ldx, in
     }
 }
 
-__device__ __forceinline__ void gf_wait_dma() {
-#ifndef CAD_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
+__device__ __forceinline__ void gf_wait_dma() { cad_wait_vmcnt<0>(); }
 
 template <int KS>
 __global__ __launch_bounds__(64 * GF_WAVES, 2) void proj_wxT_fp8_kernel(cad_proj_fp8_args a) {
@@ -231,22 +194,7 @@ __global__ __launch_bounds__(64 * GF_WAVES, 2) void proj_wxT_fp8_kernel(cad_proj
 
 }  // namespace
 
-#if defined(CAD_EMU)
-#define GF_BIG_LDS(kern, bytes) (void)0
-#else
-#define GF_BIG_LDS(kern, bytes)                                                                                      \
-    do {                                                                                                             \
-        static size_t cur[CAD_MAX_DEVICES] = {0};                                                                    \
-        int dev_ = 0;                                                                                                \
-        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= CAD_MAX_DEVICES) return CAD_ERR_LAUNCH;         \
-        if ((size_t)(bytes) > 65536 && (size_t)(bytes) > cur[dev_]) {                                                \
-            if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != \
-                hipSuccess)                                                                                          \
-                return CAD_ERR_LAUNCH;                                                                               \
-            cur[dev_] = (size_t)(bytes);                                                                             \
-        }                                                                                                            \
-    } while (0)
-#endif
+#define GF_BIG_LDS(kern, bytes) CAD_BIG_LDS(kern, bytes)
 
 extern "C" int cad_proj_fp8_supported(int K) { return K == 256 || K == 512; }
 

@@ -23,7 +23,7 @@ def build_emu(force: bool = False) -> str:
 
 def _build_emu_locked(force: bool) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "emu_runtime.*")) + \
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "emu_runtime.*")) + glob.glob(os.path.join(HERE, "*.h")) + \
         [os.path.join(ROOT, "include", "caduceus_hip.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
