@@ -203,3 +203,18 @@ def test_reference_import_name_resolves_to_this_engine():
     cfg, sd, _ = load_golden_model("ps_fused")
     model = _locate(REGISTRY_MODEL_STRING)(_locate(HYDRA_CONFIG_TARGET)(**cfg))
     assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+
+
+def test_tool_scripts_reference_existing_scripts():
+    """The evidence scripts under tools/ call each other (gpu_final.sh -> prof_scan.sh -> ...): a pruned helper must not leave a caller
+    behind (tools/prof_step_pmc.sh lost tools/step_families.py that way for a while in round 4)."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for f in glob.glob(os.path.join(root, "tools", "*.sh")) + glob.glob(os.path.join(root, "tools", "*.py")):
+        for ref in re.findall(r"tools/([A-Za-z0-9_/]+\.(?:py|sh|hip))", open(f).read()):
+            if not os.path.exists(os.path.join(root, "tools", ref)):
+                missing.append((os.path.basename(f), ref))
+    assert not missing, missing
