@@ -45,6 +45,57 @@ __global__ __launch_bounds__(512, 1) void rowstream(const uint16_t* A, long long
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// the same stream through VGPRs: every lane keeps DEPTH 16-byte loads in flight (plain global_load_dwordx4, consumed by an xor), no LDS, no
+// barrier -- is the ~3.7 TB/s ceiling of the LDS-DMA loop above a property of the access pattern or of that fetch structure?
+template <int ROWS, int PB, int DEPTH>
+__global__ __launch_bounds__(512, 1) void rowstream_vgpr(const uint16_t* A, long long ld, long long T, int nrt, long long tok_per_slice, unsigned* sink) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    constexpr int LPR = PB / 16, RPI = 512 / LPR;  // lanes per row, rows per pass of the 512 threads
+    static_assert(ROWS % RPI == 0, "rows per pass");
+    const int rt = blockIdx.x % nrt;
+    const long long sl = blockIdx.x / nrt;
+    const uint16_t* base = A + (long long)rt * ROWS * ld + sl * tok_per_slice;
+    const int nch = (int)(tok_per_slice / (PB / 2));
+    const int row0 = threadIdx.x / LPR, pp = threadIdx.x % LPR;
+    u4 acc = {0u, 0u, 0u, 0u};
+    constexpr int PASSES = ROWS / RPI;
+    for (int c = 0; c < nch; c += DEPTH) {
+        u4 v[DEPTH][PASSES];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int q = 0; q < PASSES; ++q)
+                v[d][q] = (c + d < nch) ? *(const u4*)(base + (long long)(row0 + q * RPI) * ld + (long long)(c + d) * (PB / 2) + pp * 8) : acc;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int q = 0; q < PASSES; ++q) acc ^= v[d][q];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = acc[0];
+}
+
+template <int ROWS, int PB, int DEPTH>
+static void run_vgpr(const uint16_t* A, long long M, long long T, long long ld, unsigned* sink, void* flush, size_t flush_bytes) {
+    const int nrt = (int)(M / ROWS);
+    int nsl = 256 / nrt;
+    if (nsl < 1) nsl = 1;
+    const long long tps = T / nsl;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipMemsetAsync(flush, rep, flush_bytes, 0);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((rowstream_vgpr<ROWS, PB, DEPTH>), dim3(nrt * nsl), dim3(512), 0, 0, A, ld, T, nrt, tps, sink);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    printf("VGPR loads: rows %4d x %4d B, %d chunks (%3d KB per CU) in flight, ld = T + %lld: best %.4f ms = %.2f TB/s\n", ROWS, PB, DEPTH,
+           ROWS * PB * DEPTH / 1024, ld - T, best, (double)M * T * 2 / best / 1e9);
+}
+
 template <int ROWS, int PB>
 static void run(const uint16_t* A, long long M, long long T, long long ld, unsigned* sink, void* flush, size_t flush_bytes) {
     const int nrt = (int)(M / ROWS);
@@ -73,10 +124,15 @@ int main() {
     const long long M = 1024, T = 262144;
     unsigned* sink; hipMalloc(&sink, 4);
     void* flush; const size_t fb = 600u << 20; hipMalloc(&flush, fb);
-    for (long long pad : {0LL, 64LL, 192LL}) {
+    for (long long pad : {0LL, 64LL}) {
         const long long ld = T + pad;
         uint16_t* A; hipMalloc(&A, (size_t)M * ld * 2);
         hipMemset(A, 1, (size_t)M * ld * 2);
+        run_vgpr<256, 64, 4>(A, M, T, ld, sink, flush, fb);
+        run_vgpr<256, 64, 8>(A, M, T, ld, sink, flush, fb);
+        run_vgpr<64, 256, 8>(A, M, T, ld, sink, flush, fb);
+        run_vgpr<64, 256, 16>(A, M, T, ld, sink, flush, fb);
+        run_vgpr<32, 512, 16>(A, M, T, ld, sink, flush, fb);
         run<256, 64>(A, M, T, ld, sink, flush, fb);
         run<256, 128>(A, M, T, ld, sink, flush, fb);
         run<128, 128>(A, M, T, ld, sink, flush, fb);
