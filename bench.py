@@ -58,6 +58,7 @@ def host_topology():
     thread synchronisation across sockets, and swung 4x from box to box."""
     cpus, seen = [], set()
     allowed = sorted(os.sched_getaffinity(0))
+    first_pkg = min_pkg(allowed)  # (once: one sysfs read per CPU, not per pair of CPUs)
     for c in allowed:
         base = f"/sys/devices/system/cpu/cpu{c}/topology/"
         try:
@@ -65,7 +66,7 @@ def host_topology():
             core = int(open(base + "core_id").read())
         except (OSError, ValueError):
             pkg, core = 0, c
-        if pkg == min_pkg(allowed) and (pkg, core) not in seen:
+        if pkg == first_pkg and (pkg, core) not in seen:
             seen.add((pkg, core))
             cpus.append(c)
     model = "unknown"
@@ -238,7 +239,7 @@ def scan_floor(d_model, seqlen, strands, batch):
     from caduceus_amd import _build
     if not os.path.exists(_build.FLOOR_LIB):
         return None
-    env = dict(os.environ, CADUCEUS_AMD_LIB=_build.FLOOR_LIB)
+    env = dict(os.environ, CADUCEUS_AMD_LIB=_build.FLOOR_LIB, CADUCEUS_AMD_ALLOW_TIMING_BUILD="1")  # (caduceus_amd/_lib.py refuses it otherwise)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--scan-floor-worker", str(d_model), str(seqlen), str(strands),
                           str(batch)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=False)
     if out.returncode != 0:
@@ -364,11 +365,14 @@ def main():
     # each in the kernel trace) -- with all nine kinds on, the instrumentation itself was 5 % of the step it measured
     _lib.prof_reset()
     _lib.prof_enable(True, kinds=("scan_fwd", "scan_bwd"))
+    reducer.time_exposed = use_dist  # two event records per step: how long the compute stream waits for all-reduces backward did not hide
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    reducer.time_exposed = False
+    exposed = reducer.exposed_ms()
     _lib.prof_enable(False)
     prof = _lib.prof_read()
     _lib.prof_reset()
@@ -379,10 +383,21 @@ def main():
     _lib.prof_enable(False)
     prof_all = _lib.prof_read()
     _lib.prof_reset()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, sum(exposed) / max(1, len(exposed))], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, exposed_ms = float(t[0].item()), float(t[1].item())
+    dist_info = {"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
+                 "collective_library": None, "grad_allreduce_bytes_per_step": sum(b.numel() * 4 for b in reducer.buckets),
+                 "buckets": len(reducer.buckets),
+                 # MAX over ranks of the mean time the compute stream spent inside reducer.finish(): the part of the gradient
+                 # all-reduce that backward did not hide (+ the launch of late buckets); null without a process group
+                 "allreduce_exposed_ms_per_step": exposed_ms if use_dist else None}
+    if use_dist and not emu:
+        try:
+            dist_info["collective_library"] = "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as ex:  # noqa: BLE001
+            dist_info["collective_library"] = repr(ex)
 
     if rank == 0:
         tokens = args.batch * args.seqlen * world * args.steps * accum
@@ -463,8 +478,8 @@ def main():
             proj = {"kernel": "in_proj GEMM (" + ("cad_proj_wxT, own bf16 MFMA kernel" if own else "hipBLASLt") + ")", "ms": ms,
                     "TFLOPs": fl / ms / 1e9, "mfma_peak_TFLOPs": 2500.0 if args.dtype == "bf16" else 157.3,
                     "GBps": by / ms / 1e6, "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS,
-                    "note": "K = d_model: HBM-bound (arithmetic intensity ~200 flop/B), not MFMA-bound; MFMA-busy counters "
-                            "in profiles/r02_proj_pmc_summary.txt"}
+                    "note": "K = d_model: HBM-bound (arithmetic intensity ~200 flop/B), not MFMA-bound; per-kernel MFMA-busy and "
+                            "fabric-byte counters of the whole step in profiles/r04_step_pmc_summary.txt"}
             if args.fp8_proj and _ops.fp8_proj_supported(xx, args.d_model):
                 wq, sw = _ops.quant_weight_fp8(ww)
                 xq, sx = _ops.quant_rows_fp8(xx)
@@ -524,7 +539,7 @@ def main():
                        "global_batch": args.batch * world * accum, "accumulate_grad_batches": accum,
                        "seq_len": args.seqlen, "parallelism": f"dp{world}",
                        "params": n_params, "final_loss": float(loss.detach())},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "dist": dist_info, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -66,6 +66,8 @@ def build_hip(force: bool = False, verbose: bool = True, defines=(), out: str = 
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-pass-failed"]
     flags += [f"-D{d}" for d in defines] + list(extra_flags) + [f'-DCAD_SRC_HASH="{source_hash(defines)}"']
+    if defines:  # cad_version() names the tuning defines of a variant build (and marks timing builds: csrc/api.hip)
+        flags.append('-DCAD_VARIANT="' + ",".join(sorted(defines)) + '"')
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

@@ -193,6 +193,12 @@ def _bind(path: str):
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    # a timing build (-DSC_WHATIF / -DSC_TIMING: kernels cut down for measurements, WRONG results by construction) says so in
+    # cad_version() (csrc/api.hip) and is never loaded as the product: only the measurement tools opt in
+    ver = lib.cad_version().decode()
+    if "TIMING-BUILD" in ver and os.environ.get("CADUCEUS_AMD_ALLOW_TIMING_BUILD") != "1":
+        raise RuntimeError(f"{path} is a timing build ({ver}): its kernels produce wrong results by construction. It is loaded only "
+                           "with CADUCEUS_AMD_ALLOW_TIMING_BUILD=1 (bench.py's floor worker, tools/ab_layer.sh).")
     return lib
 
 

@@ -4,14 +4,27 @@
 
 #include "cad_common.h"
 
+// A build with -D tuning defines says so (CAD_VARIANT = the define list, caduceus_amd/_build.py); a build whose kernels were cut down for
+// TIMING experiments (-DSC_WHATIF=<bits> / -DSC_TIMING: wrong results by construction) carries the marker the loader refuses
+// (caduceus_amd/_lib.py: only with CADUCEUS_AMD_ALLOW_TIMING_BUILD=1, which bench.py's floor worker and the A/B tools set).
+#if (defined(SC_WHATIF) && SC_WHATIF != 0) || defined(SC_TIMING)
+#define CAD_TIMING_TAG " TIMING-BUILD (wrong results by construction; never the product)"
+#else
+#define CAD_TIMING_TAG ""
+#endif
+#ifdef CAD_VARIANT
+#define CAD_VARIANT_TAG " variant[" CAD_VARIANT "]"
+#else
+#define CAD_VARIANT_TAG ""
+#endif
 extern "C" const char* cad_version(void) {
 #ifdef CAD_EMU
     return "caduceus_amd 0.1.0 (host emulator build - tests only)";
 #else
 #ifdef CAD_SRC_HASH
-    return "caduceus_amd 0.1.0 (hip gfx950) src " CAD_SRC_HASH;
+    return "caduceus_amd 0.1.0 (hip gfx950) src " CAD_SRC_HASH CAD_VARIANT_TAG CAD_TIMING_TAG;
 #else
-    return "caduceus_amd 0.1.0 (hip gfx950)";
+    return "caduceus_amd 0.1.0 (hip gfx950)" CAD_VARIANT_TAG CAD_TIMING_TAG;
 #endif
 #endif
 }
@@ -29,6 +42,21 @@ extern "C" const char* cad_status_string(int s) {
 }
 
 int cad_after_launch() { return hipGetLastError() == hipSuccess ? CAD_OK : CAD_ERR_LAUNCH; }
+
+int cad_cu_count() {
+#ifdef CAD_EMU
+    return 256;
+#else
+    static int cus[CAD_MAX_DEVICES] = {0};  // (benign race: every thread writes the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CAD_MAX_DEVICES) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+#endif
+}
 
 namespace {
 std::mutex g_mu;

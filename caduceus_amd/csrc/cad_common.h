@@ -88,6 +88,8 @@ __device__ __forceinline__ int64_t cad_phys(int64_t p, int64_t L, int rev) { ret
     } while (0)
 
 int cad_after_launch();  // hipGetLastError -> cad_status
+int cad_cu_count();      // compute units of the current device (queried once per device; 256 on the host emulator / on failure): the
+                         // "one workgroup per CU" launchers size their grids with it, as the python side sizes the work (ops._cu_count)
 
 // RAII kernel timer (no-op unless cad_prof_enable(1)); see api.hip
 struct CadProfScope {

@@ -36,6 +36,20 @@ __device__ __forceinline__ float cad_rsqrt(float x) {
     return __builtin_amdgcn_rsqf(x);
 }
 
+// v_perm_b32: every byte of the result is picked by the matching selector byte from the 8 bytes {s0[3..0], s1[3..0]} -- selector values
+// 0..3 = bytes 0..3 of s1, 4..7 = bytes 0..3 of s0, 0x0c = the constant 0x00.  One instruction selects a dword, swaps its halves and / or
+// widens one bf16 half to fp32 (selector 0x..0c0c: the half lands in bits [31:16] over zero bits).
+__device__ __forceinline__ uint32_t cad_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    return __builtin_amdgcn_perm(s0, s1, sel);
+}
+
+// v_mul_legacy_f32: a product in which 0 * anything (inf, NaN) is 0
+__device__ __forceinline__ float cad_mul_legacy(float a, float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---- cross-lane primitives (DPP on gfx950; emulated through the fiber exchange in the test build) -----------------
 // Each returns, per lane, the value of `v` in the source lane selected by the pattern, or `old` where the pattern has
 // no source for this lane -- exactly v_mov_b32_dpp with bound_ctrl:0.  Passing the identity element as `old` lets a

@@ -955,7 +955,7 @@ static int launch_wxT(const cad_proj_args* a, void* stream) {
     typedef GpCfg<KS> C;
     const int64_t nblk = (a->T + C::NT - 1) / C::NT;
     const int my = (a->M + C::MWG - 1) / C::MWG;
-    int64_t gx = 256 / my;  // ~ one workgroup per CU
+    int64_t gx = cad_cu_count() / my;  // ~ one workgroup per CU
     if (gx < 1) gx = 1;
     if (gx > nblk) gx = nblk;
     dim3 grid((unsigned)gx, (unsigned)my), block(64 * GP_WAVES);
@@ -985,7 +985,7 @@ static int launch_wx(const cad_proj_args* a, void* stream) {
     typedef GxCfg<KS> C;
     const int64_t nblk = (a->T + C::NT - 1) / C::NT;
     const int my = (a->M + C::MWG - 1) / C::MWG;
-    int64_t gx = 256 / my;
+    int64_t gx = cad_cu_count() / my;
     if (gx < 1) gx = 1;
     if (gx > nblk) gx = nblk;
     dim3 grid((unsigned)gx, (unsigned)my), block(64 * GP_WAVES);
@@ -1009,7 +1009,7 @@ extern "C" int cad_proj_wx_thin_supported(int M, int K, int64_t T) {
 template <int MB>
 static int launch_wx_thin(const cad_proj_args* a, void* stream) {
     const int64_t nblk = (a->T + GtCfg::NT - 1) / GtCfg::NT;
-    int64_t gx = 256;  // one workgroup per CU
+    int64_t gx = cad_cu_count();  // one workgroup per CU
     if (gx > nblk) gx = nblk;
     const size_t lds = GtCfg::lds(MB * 16, a->K);
     dim3 grid((unsigned)gx), block(64 * GP_WAVES);
@@ -1109,7 +1109,7 @@ extern "C" int cad_proj_xTw_supported(int M, int K, int64_t T) {
 template <int MB, int KS>
 static int launch_xTw(const cad_proj_tm_args* a, void* stream) {
     const int64_t nblk = (a->T + GtCfg::NT - 1) / GtCfg::NT;
-    int64_t gx = 256;  // one workgroup per CU
+    int64_t gx = cad_cu_count();  // one workgroup per CU
     if (gx > nblk) gx = nblk;
     const size_t lds = (size_t)GP_XTW_RING * GtCfg::XBUF;
     dim3 grid((unsigned)gx), block(64 * GP_WAVES);
@@ -1143,7 +1143,7 @@ extern "C" int cad_gemm_stream(const cad_gemm_stream_args* a, void* stream) {
     CAD_CHECK_ARG(a->mode == CAD_GEMM_PARTIALS || (a->nslices == 1 && a->ldo >= a->R && (a->ldo % 4) == 0 && ((uintptr_t)a->out % 8) == 0));
     CadProfScope prof(8, stream);
     const int64_t nitems = (a->R / GsCfg::RT) * (a->C / GsCfg::CT) * a->nslices;
-    int64_t gx = 256;  // one workgroup per CU
+    int64_t gx = cad_cu_count();  // one workgroup per CU
     if (gx > nitems) gx = nitems;
     dim3 grid((unsigned)gx), block(64 * GP_WAVES);
     if (a->mode == CAD_GEMM_PARTIALS) {

@@ -225,7 +225,7 @@ static int launch_fp8(const cad_proj_fp8_args* a, void* stream) {
     typedef GfCfg<KS> C;
     const int64_t nblk = (a->T + C::NT - 1) / C::NT;
     const int my = (a->M + C::MWG - 1) / C::MWG;
-    int64_t gx = 256 / my;
+    int64_t gx = cad_cu_count() / my;
     if (gx < 1) gx = 1;
     if (gx > nblk) gx = nblk;
     dim3 grid((unsigned)gx, (unsigned)my), block(64 * GF_WAVES);

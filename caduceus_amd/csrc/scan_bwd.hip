@@ -82,14 +82,37 @@ static_assert(SC_S_BWD == 8, "the backward scan is written for 8 items per lane 
 #ifndef SC_BWD_UNROLL_NP
 #define SC_BWD_UNROLL_NP 8
 #endif
+#ifndef SC_BWD_LEAN
+#define SC_BWD_LEAN 1   // 0: the round-4 prologue / epilogue / per-pair-step dA wave sum for every launch (A/B switch)
+#endif
 static_assert(SC_W == 4 || SC_W == 8, "staging needs >= 256 threads; the flush mapping is written for 256 / 512");
 
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1])); }
 
+// sigmoid(raw delta) recovered from dt = softplus(raw delta): 1 - exp(-dt).  Results that are rounded to bf16 take the two-term series
+// dt (1 - dt / 2) below 2^-9 (relative error dt^2 / 6 < 7e-7 there; above it 1 - exp(-dt) carries at most 2^-24 / 2^-9 = 3e-5) -- 5 VALU
+// + 1 transcendental per item instead of the fp32 form's 10 + 1 (cad_sigmoid_from_softplus: four-term series below 1 / 16).
+template <typename T>
+__device__ __forceinline__ float sc_sigmoid_from_dt(float dt) {
+    if constexpr (sizeof(T) == 2) {
+        const float small = dt * (1.0f - 0.5f * dt);
+        const float big = 1.0f - cad_exp(-dt);
+        return dt < 0.001953125f ? small : big;
+    } else {
+        return cad_sigmoid_from_softplus(dt);
+    }
+}
+
 // CO = carry-only instantiation (cad_scan_bwd_args.carry_only, pass 1 of an L-split backward): the reverse recurrence of the
 // state gradient alone -- exp, C * dy, one chain per item and state, the reverse wave scan -- and dh0 as its only output.  A
 // separate instantiation, so the full kernel carries none of its branches (measured: +5 % when they were run-time branches).
-template <typename T, bool VEC, bool CO, int NPC = 0>
+// ISDT = every set's delta already holds dt (cad_scan_bwd_args.delta_is_dt, the production path: softplus in the dt_proj epilogue) as a
+// COMPILE-TIME fact of the unrolled production instantiation.  Together with the LDS-DMA prefetch it selects the LEAN chunk prologue /
+// epilogue (round 5): a lane outside the row is silenced by dt = 0 and dy = 0 alone (every contribution vanishes by arithmetic, no
+// per-item select), direction + widening of an item is one v_perm_b32, dt comes from the (dt, dt u) pairs (the raw delta vector is dead
+// after the prologue), the accumulators start from the first pair's products instead of zeros, and dA is summed inside 8-lane groups per
+// pair-step and across the groups once per kernel.  Static count of a 512-position chunk: see profiles/r05_scan_isa_mix.txt.
+template <typename T, bool VEC, bool CO, int NPC = 0, bool ISDT = false>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][wave][dB,dC][ACC_TILE] contributions
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
@@ -103,6 +126,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     // [vector 0..5][wave][lane][16 bytes], behind the two slab buffers (a carry-only pass has no slab: 68 KB of LDS in all, so two
     // of its workgroups -- 92 VGPRs -- share a CU)
     char* pre = CO ? (char*)acc : (char*)(accp + 2 * PK_BUF);
+    constexpr bool LEAN = PREF && ISDT && !CO && NPC != 0;
+    static_assert(!ISDT || LEAN, "ISDT is the production instantiation's switch");
     const int lane = threadIdx.x & 63;
     // selection matrix of the MFMA flush (see PK_TILE): row i = lane & 15 picks element pi(i & 7) of every piece
     u32x4 selA = {0u, 0u, 0u, 0u};
@@ -133,7 +158,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const T* Bm = (const T*)a.Bm;
     const T* Cm = (const T*)a.Cm;
     const float Dv = a.D ? a.D[e] : 0.f;
-    const bool is_dt = a.delta_is_dt != 0;  // wave-uniform: delta already holds dt = softplus(delta_raw + bias)
+    const bool is_dt = ISDT || a.delta_is_dt != 0;  // wave-uniform: delta already holds dt = softplus(delta_raw + bias)
+    const ScDirSel dsel = sc_dir_sel(rev);
     const float bias = (a.delta_bias && !is_dt) ? a.delta_bias[e] : 0.f;
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const float keep = act ? 1.f : 0.f;  // padding waves (E % SC_W != 0) contribute nothing
@@ -206,7 +232,29 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
-        if constexpr (PREF) {
+        if constexpr (LEAN) {
+            // this chunk's vectors were fetched into LDS one chunk ago.  A lane's segment lies inside the row or outside it as a whole;
+            // outside, dt = 0 and dy = 0 make every contribution of the lane vanish by arithmetic (a = 1, b = 0, g = G, dB = dC = 0,
+            // dA term = t * 0, d(delta) = (..) * (1 - exp(-0))), so ONLY these two vectors are masked -- the clamped prefetch address
+            // delivers finite data of the row start for the others -- and no per-item select is left.  dy = 0 also silences a padding
+            // wave (E % SC_W != 0: its state-gradient carry starts from 0, so g stays 0).
+            sc_wait_loads<SC_PRE_WAIT ? 3 : 0>();
+            const char* slot = pre + wave * (64 * 16) + lane * 16;
+            typedef ScVec<T, SC_S> V;
+            const uint32_t inm = p0 < L ? 0xffffffffu : 0u, livem = (p0 < L && act) ? 0xffffffffu : 0u;
+            auto rd = [&](int k, uint32_t m) {
+                u32x4 v = *(const u32x4*)(slot + k * PRE_SLOT);
+                v[0] &= m, v[1] &= m, v[2] &= m, v[3] &= m;
+                return __builtin_bit_cast(V, v);
+            };
+            auto rd_raw = [&](int k) { return __builtin_bit_cast(V, *(const u32x4*)(slot + k * PRE_SLOT)); };
+            u_raw = rd_raw(0);
+            d_raw = rd(1, inm);
+            g_raw = rd(2, livem);
+            if (z_row) z_raw = rd_raw(3);
+            if (o_row) o_raw = rd_raw(4);
+            if (o2_row) o2_raw = rd_raw(5);
+        } else if constexpr (PREF) {
             // this chunk's vectors were fetched into LDS one chunk ago
             sc_wait_loads<SC_PRE_WAIT ? 3 : 0>();
             const char* slot = pre + wave * (64 * 16) + lane * 16;
@@ -227,7 +275,60 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if (o_row) o_raw = rd(4);
             if (o2_row) o2_raw = rd(5);
         }
-        {
+        if constexpr (LEAN) {
+            float uu[SC_S], dt[SC_S], dy[SC_S];
+            sc_unpack_p<T, SC_S>(u_raw, rev, dsel, uu);
+            sc_unpack_p<T, SC_S>(d_raw, rev, dsel, dt);
+            sc_unpack_p<T, SC_S>(g_raw, rev, dsel, dy);
+            if (z_row) {
+                // gate: dy <- dout * silu(z), and the gate gradient right away (it needs nothing from the scan):
+                // out = y z sigmoid(z)  =>  y sigmoid(z) = out / z ;  dz = dout * (out / z) * (1 + z - z sigmoid(z))
+                float zz[SC_S];
+                sc_unpack_p<T, SC_S>(z_raw, rev, dsel, zz);
+                if (a.gate_fix_list) {
+                    // out / z cannot recover y where the gate is exactly 0 (out == 0 there): remember the chunk, the fix-up launch
+                    // (cad_scan_bwd_gate_fix) recomputes y for it and adds dout * y / 2 to dz.  min |z| over the lane's items == 0.
+                    float zmin = __builtin_fabsf(zz[0]);
+#pragma unroll
+                    for (int i = 1; i < SC_S; ++i) zmin = __builtin_fminf(zmin, __builtin_fabsf(zz[i]));
+                    if (cad_wave_any(zmin == 0.f && p0 < L && act) && lane == 0) {
+                        const int slot = atomicAdd(a.gate_fix_count, 1);
+                        a.gate_fix_list[slot] = (int64_t)e | ((int64_t)sb << 20) | ((int64_t)c << 40);
+                    }
+                }
+                if (o_row) {  // wave-uniform: this set writes the gate gradient (of both scans sharing the gate when out2 is given)
+                    float oo[SC_S], dzv[SC_S];
+                    sc_unpack_p<T, SC_S>(o_raw, rev, dsel, oo);
+                    if (o2_row) {
+                        float o2[SC_S];
+                        sc_unpack_p<T, SC_S>(o2_raw, rev, dsel, o2);
+#pragma unroll
+                        for (int i = 0; i < SC_S; ++i) oo[i] += o2[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < SC_S; ++i) {
+                        const float sg = cad_sigmoid(zz[i]);
+                        // (legacy product: 0 where out == 0, i.e. also at z == 0 where 1 / z is inf -- the value the fix-up launch adds to)
+                        const float ys = cad_mul_legacy(oo[i], cad_rcp(zz[i]));
+                        const float silu = zz[i] * sg;
+                        dzv[i] = dy[i] * ys * ((1.f + zz[i]) - silu);
+                        dy[i] *= silu;
+                    }
+                    if (act && !(SC_WHATIF & 2048))
+                        sc_by_dir(rev, [&](auto rtag) { sc_store_d<T, SC_S, VEC, decltype(rtag)::value != 0>(dz_row, p0, L, dzv); });
+                } else {
+#pragma unroll
+                    for (int i = 0; i < SC_S; ++i) dy[i] *= zz[i] * cad_sigmoid(zz[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SC_S; ++i) {
+                dDacc += dy[i] * uu[i];
+                dd[i] = f2(dt[i], dt[i] * uu[i]);
+                sum_dt += dt[i];
+                dy2[i >> 1][i & 1] = dy[i];
+            }
+        } else {
             float uu[SC_S], dt[SC_S], dy[SC_S];
             sc_unpack<T, SC_S>(u_raw, rev, uu);
             sc_unpack<T, SC_S>(d_raw, rev, dt);
@@ -307,6 +408,28 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         // With the LDS-DMA prefetch nothing overwrites those registers, so it runs once BEHIND the pair loop (inside the
         // loop the compiler if-converts it and evaluates its transcendentals in every pair-step).
         auto chunk_epilogue = [&]() {
+            if constexpr (LEAN) {
+                // dt is the low half of the (dt, dt u) pairs; u is widened again from its raw vector (4 registers across the pair loop
+                // instead of 8); sigmoid(raw delta) = 1 - exp(-dt).  A lane outside the row has dt = 0, hence d(delta) = (..) * 0 and
+                // du = 0 * <g, B> + 0 * D: no select
+                float uu[SC_S], du[SC_S];
+                sc_unpack_p<T, SC_S>(u_raw, rev, dsel, uu);
+#pragma unroll
+                for (int i = 0; i < SC_S; ++i) {
+                    const float dti = dd[i][0];
+                    const float sg = sc_sigmoid_from_dt<T>(dti);
+                    du[i] = dti * gBs[i] + dy2[i >> 1][i & 1] * Dv;
+                    ddt[i] = (ddt[i] + uu[i] * gBs[i]) * sg;
+                    dbacc += ddt[i];
+                }
+                if (act && !(SC_WHATIF & 2048)) {
+                    sc_by_dir(rev, [&](auto rtag) {
+                        sc_store_d<T, SC_S, VEC, decltype(rtag)::value != 0>(du_row, p0, L, du);
+                        sc_store_d<T, SC_S, VEC, decltype(rtag)::value != 0>(dd_row, p0, L, ddt);
+                    });
+                }
+                return;
+            }
             float uu[SC_S], dl[SC_S], du[SC_S];
             sc_by_dir(rev, [&](auto rtag) {
                 sc_unpack_d<T, SC_S, decltype(rtag)::value != 0>(u_raw, uu);
@@ -438,8 +561,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 G = av[i] * g;
                 const f32x2 hprev = (i > 0) ? hs[i > 0 ? i - 1 : 0] : h0;
                 const f32x2 t = G * hprev;  // g * a_i * h_{i-1}
-                ddt[i] = dot2_acc(ddt[i], t, Av);  // scalar accumulators: the packed form (one v_pk_fma each) needs 16 more
-                gBs[i] = dot2_acc(gBs[i], g, Bv);  // VGPRs, spills, and the spill traffic reaches HBM (+0.75 GB per launch)
+                if (LEAN && np == 0) {  // (compile-time after unrolling: the first pair's products start the chunk's sums)
+                    ddt[i] = dot2_first(t, Av);
+                    gBs[i] = dot2_first(g, Bv);
+                } else {
+                    ddt[i] = dot2_acc(ddt[i], t, Av);  // scalar accumulators: the packed form (one v_pk_fma each) needs 16 more
+                    gBs[i] = dot2_acc(gBs[i], g, Bv);  // VGPRs, spills, and the spill traffic reaches HBM (+0.75 GB per launch)
+                }
                 dAp = dAp + t * splat_lo(dd[i]);
                 const f32x2 dBv = g * splat_hi(dd[i]);
                 const f32x2 dCv = hs[i] * SC_DY(i);
@@ -465,8 +593,13 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 }
             }
             SC_TIME(7);  // gradient loop + slab writes
-            dAp = wave_sum2_dpp(dAp);
-            if (lane == np) dAacc = dAacc + dAp * f2(keep);
+            if constexpr (LEAN) {
+                // sum inside the 8-lane groups now (3 DPP steps), across the 8 groups once per kernel: lane 8 g + np collects pair np
+                add_on_lanes_mod8(dAacc, group8_sum2_dpp(dAp), np);
+            } else {
+                dAp = wave_sum2_dpp(dAp);
+                if (lane == np) dAacc = dAacc + dAp * f2(keep);
+            }
             if constexpr (!PREF && !CO) {
                 // (register prefetch: the next chunk's vectors overwrite u_raw / d_raw behind this pair's barrier)
                 if (np == NP - 1) chunk_epilogue();
@@ -591,6 +724,10 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         if (2 * lane + 1 < N) gp[1] = carryG[1];
     }
     if constexpr (CO) return;  // nothing else is an output of a carry-only pass
+    if constexpr (LEAN) {  // lanes 8 g + np hold group g's share of pair np: fold the groups, lane np ends up with the wave's sum
+#pragma unroll
+        for (int m = 8; m <= 32; m <<= 1) dAacc = dAacc + f2(__shfl_xor(dAacc[0], m), __shfl_xor(dAacc[1], m));
+    }
     // per-channel parameter gradients (E x N, E: a few device-scope atomics per wave, once per kernel)
     if (act && lane < NP) {
         const int n0 = 2 * lane;
@@ -801,12 +938,18 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
     const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
+    bool all_dt = true;  // every set hands over dt itself: the lean production instantiation (ISDT)
+    for (int i = 0; i < nsets; ++i) all_dt = all_dt && sets[i].delta_is_dt != 0;
     const size_t slab_floats = a->carry_only ? 0 : (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF);
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + slab_floats) * sizeof(float) +
                          (pref ? PRE_BYTES : 0);
 #define SC_BWD_LAUNCH(T, V)                                                                  \
     do {                                                                                     \
-        if (SC_BWD_UNROLL_NP && !a->carry_only && V && sizeof(T) == 2 && a->N == 2 * SC_BWD_UNROLL_NP) { \
+        if (SC_BWD_UNROLL_NP && SC_BWD_LEAN && !a->carry_only && V && sizeof(T) == 2 && pref && all_dt &&   \
+            a->N == 2 * SC_BWD_UNROLL_NP) {                                                  \
+            SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2>), shmem);             \
+            CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2>), grid, block, shmem, stream, ks); \
+        } else if (SC_BWD_UNROLL_NP && !a->carry_only && V && sizeof(T) == 2 && a->N == 2 * SC_BWD_UNROLL_NP) { \
             SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP>), shmem);             \
             CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP>), grid, block, shmem, stream, ks); \
         } else if (a->carry_only) {                                                          \

@@ -283,6 +283,39 @@ __device__ __forceinline__ void sc_store_d(T* row, int64_t p0, int64_t L, const 
         sc_store<T, S, VEC>(row, p0, L, REV ? 1 : 0, v);
     }
 }
+// Direction select + bf16 -> fp32 widening of an item in ONE v_perm_b32 (cad_perm): logical item j of a right-to-left row is physical
+// element S-1-j, i.e. the OTHER half of dword NW-1-q -- which dword and which half are a byte selector, wave-uniform (SGPR), so an
+// 8-item vector unpacks in 8 VALU instructions for either direction without a branch (select + rotate + widen: 16; branched: 8).
+struct ScDirSel {
+    uint32_t even, odd;  // selectors of logical items 2q / 2q + 1 from {s0 = w[NW-1-q], s1 = w[q]}
+};
+__device__ __forceinline__ ScDirSel sc_dir_sel(int rev) {
+    ScDirSel r;
+    r.even = (uint32_t)cad_uniform((int)(rev ? 0x07060c0cu : 0x01000c0cu));  // rev: high half of s0;  fwd: low half of s1
+    r.odd = (uint32_t)cad_uniform((int)(rev ? 0x05040c0cu : 0x03020c0cu));   // rev: low half of s0;   fwd: high half of s1
+    return r;
+}
+template <typename T, int S>
+__device__ __forceinline__ void sc_unpack_p(const ScVec<T, S>& raw, int rev, ScDirSel sel, float* out) {
+    if constexpr (sizeof(T) == 2 && S % 2 == 0) {
+        constexpr int NW = S / 2;
+#ifdef CAD_EMU
+        struct W { uint32_t w[NW]; };
+        const W ww = __builtin_bit_cast(W, raw);
+        const uint32_t* w = ww.w;
+#else
+        typedef uint32_t uw __attribute__((ext_vector_type(NW)));
+        const uw w = __builtin_bit_cast(uw, raw);
+#endif
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            out[2 * q] = cad_bits2f(cad_perm(w[NW - 1 - q], w[q], sel.even));
+            out[2 * q + 1] = cad_bits2f(cad_perm(w[NW - 1 - q], w[q], sel.odd));
+        }
+    } else {
+        sc_unpack<T, S>(raw, rev, out);
+    }
+}
 template <typename F>
 __device__ __forceinline__ void sc_by_dir(int rev, F&& f) {
     if (cad_uniform(rev)) {

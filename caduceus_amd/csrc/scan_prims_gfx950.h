@@ -29,6 +29,46 @@ __device__ __forceinline__ float dot2_acc(float acc, f32x2 a, f32x2 b) {
     return acc;
 }
 
+// The first dot product of an accumulation (v_mul + v_fmac): no zero-initialised accumulator register, no v_mov
+__device__ __forceinline__ float dot2_first(f32x2 a, f32x2 b) {
+    float acc;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(acc) : "v"(a[0]), "v"(b[0]));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a[1]), "v"(b[1]));
+    return acc;
+}
+
+// Sums inside every group of 8 consecutive lanes (each of the 8 lanes receives its group's sum), two values at once: a butterfly of
+// three DPP steps -- lane ^ 1, lane ^ 2 (quad_perm), then the mirrored lane of the 8-lane half row, which sits in the other quad and
+// therefore holds the other quad's sum.  Half of a wave-wide sum; the caller accumulates the group sums per group and folds the
+// eight groups ONCE per kernel (the backward scan's dA).
+__device__ __forceinline__ f32x2 group8_sum2_dpp(f32x2 v) {
+    float x = v[0], y = v[1];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(x), "+v"(y));
+    return f2(x, y);
+}
+
+// acc += x on the lanes with (lane & 7) == k, k = 0..7: exec = 0x01010101 << k in both halves (every lane of the wave is active on
+// entry: wave-uniform trip counts)
+__device__ __forceinline__ void add_on_lanes_mod8(f32x2& acc, f32x2 x, int k) {
+    const uint32_t m = 0x01010101u << k;
+    asm volatile(
+        "s_mov_b32 exec_lo, %2\n\t"
+        "s_mov_b32 exec_hi, %2\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(acc)
+        : "v"(x), "s"(m));
+}
+
 // Two wave-wide sums at once, the two DPP chains interleaved by hand: a DPP read needs two wait states after the VALU
 // write of its source, so one chain alone is padded with an s_nop before every step (and the compiler emits the two
 // chains one after the other); interleaved, each chain's step fills the other's wait states.

@@ -64,6 +64,10 @@ class BucketedGradReducer:
             self.buckets.append(flat)
         self._sizes = [len(g) for g in groups]
         self._reset_counters()
+        # measurement aid (bench.py): time every finish() -- on a GPU as a pair of events on the compute stream, i.e. how long that
+        # stream had to wait for all-reduces that backward did NOT hide (the exposed part); on CPU as host time
+        self.time_exposed = False
+        self._exposed = []
 
     def _reset_counters(self):
         self._pending = list(self._sizes)
@@ -114,6 +118,35 @@ class BucketedGradReducer:
         if not self.sync_enabled:
             raise RuntimeError("BucketedGradReducer.finish() inside no_sync(): call it after the last micro-step, outside the "
                                "context (the all-reduce would be skipped silently)")
+        mark = self._mark() if self.time_exposed else None
+        self._finish()
+        if mark is not None:
+            self._exposed.append((mark, self._mark()))
+
+    def _mark(self):
+        dev = self.buckets[0].device if self.buckets else torch.device("cpu")
+        if dev.type == "cuda":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(dev))
+            return e
+        import time
+        return time.perf_counter()
+
+    def exposed_ms(self, reset: bool = True) -> List[float]:
+        """Per finish() since the last reset: milliseconds between entering and leaving it on the compute stream (GPU: the wait for
+        all-reduces still in flight after backward + the launch of buckets that never triggered; synchronises)."""
+        out = []
+        for a, b in self._exposed:
+            if isinstance(a, float):
+                out.append((b - a) * 1e3)
+            else:
+                b.synchronize()
+                out.append(a.elapsed_time(b))
+        if reset:
+            self._exposed = []
+        return out
+
+    def _finish(self):
         for bi in range(len(self.buckets)):
             if self._pending[bi] != 0:
                 self._gather(bi)

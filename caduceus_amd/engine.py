@@ -12,7 +12,8 @@ duplicated in/out projections.  Here:
   * activations between GEMMs and scans are channel-major (E, S*B, L): the in_proj GEMM writes that layout directly
     (W @ X^T) and every scan/conv access is a contiguous run along L.
 
-The GEMMs are plain dense projections and go to hipBLASLt through torch.mm (MFMA); everything else is our HIP.
+On THIS (generic, per-op autograd) path the dense projections are torch.mm / hipBLASLt; the production configuration (tied, "add") runs
+mixer.BiMambaMixerFn instead, whose projections are the library's own MFMA kernels (csrc/gemm.hip) -- no library GEMM on that step.
 """
 from __future__ import annotations
 

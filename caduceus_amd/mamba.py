@@ -154,7 +154,7 @@ class Block(nn.Module):
 
     def forward_tframe(self, hidden: torch.Tensor, residual: Optional[torch.Tensor], act: torch.dtype):
         w, b, eps, is_rms = norm_params(self.norm)
-        hn, residual = ops.add_norm(hidden, residual, w, b, eps, is_rms, False, act)
+        hn, residual = ops.add_norm(hidden, residual, w, b, eps, is_rms, False, act, want_fp8=True)  # (feeds the mixer's in_proj)
         return self.mixer.forward_tframe(hn, strand_swap=False), residual
 
     def forward(self, hidden_states, residual=None, inference_params=None):

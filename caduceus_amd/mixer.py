@@ -195,7 +195,9 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
         alog += [mf.A_log.detach().float(), mr.A_log.detach().float()]
         owners.append((mf, ps + [mf.A_log, mr.A_log], out))
     torch._foreach_copy_(dst, src)
-    trans = {kd: stacked[kd].transpose(1, 2).contiguous() for kd in ("out", "x", "dt", "in") if kd in stacked}
+    # (W_in^T feeds cad_gemm_stream's d(x2d) only: d_model <= 256 with the own tiled GEMM on)
+    need_in_T = _OWN_GEMM and "in" in stacked and stacked["in"].shape[2] <= 256
+    trans = {kd: stacked[kd].transpose(1, 2).contiguous() for kd in ("out", "x", "dt") + (("in",) if need_in_T else ()) if kd in stacked}
     cursor = {kd: 0 for kd in kinds}
 
     def transposed(kd, w):
@@ -207,7 +209,8 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
 
     for mf, ps, out in owners:
         # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T, W_in^T], in the order the stacked buffers were filled
-        out.append([transposed(kd, out[j]) for kd, j in (("out", 1), ("x", 2), ("dt", 3), ("x", 4), ("dt", 5), ("in", 0))])
+        out.append([transposed(kd, out[j]) for kd, j in (("out", 1), ("x", 2), ("dt", 3), ("x", 4), ("dt", 5))] +
+                   [transposed("in", out[0]) if need_in_T else None])
     negA = torch._foreach_exp(alog)
     torch._foreach_neg_(negA)
     for i, (mf, ps, out) in enumerate(owners):
@@ -385,6 +388,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             dBC_ = work[i][5]
             jobs[2 * i] = L.ReduceJob(L.ptr(dBC_[0]), L.ptr(ddbcs[i][R_:R_ + N_]))
             jobs[2 * i + 1] = L.ReduceJob(L.ptr(dBC_[1]), L.ptr(ddbcs[i][R_ + N_:]))
+        assert work[0][6] == work[1][6] and sets[0][2].shape[1] == sets[1][2].shape[1], "one fold launch: both sets share depth and d_state"
         L.check(lib.cad_reduce_partials_multi(jobs, 4, work[0][6], sets[0][2].shape[1] * SB * Lq, L.dtype_code(act), stream),
                 "cad_reduce_partials_multi")
         for i in range(2):
@@ -447,7 +451,10 @@ class BiMambaMixerFn(torch.autograd.Function):
             dxz[E:].add_(dz_r)
         # (d_model 256: one 256-row tile, dxz read once; the configs[4] step with all three products on the own kernel measured 570.7 ms
         # against 555.9 ms with the library: d_model 512 stays there)
-        dx2d = ops.proj_xTw_stream(wT["in"] if wT else w_in.t().contiguous(), dxz.view(2 * E, T)) if _OWN_GEMM and Dm <= 256 else None
+        dx2d = None
+        if _OWN_GEMM and Dm <= 256:
+            w_inT = wT["in"] if (wT and wT.get("in") is not None) else w_in.t().contiguous()
+            dx2d = ops.proj_xTw_stream(w_inT, dxz.view(2 * E, T))
         if dx2d is None:
             dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
         dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
@@ -472,7 +479,7 @@ def bimamba_mixer(hn: torch.Tensor, mamba_fwd, mamba_rev, split: int) -> torch.T
     cache = _cached(mamba_fwd, [mamba_fwd.in_proj.weight, mamba_fwd.out_proj.weight, mamba_fwd.x_proj.weight,
                                 mamba_fwd.dt_proj.weight, mamba_rev.x_proj.weight, mamba_rev.dt_proj.weight,
                                 mamba_fwd.A_log, mamba_rev.A_log])
-    fp8_act = getattr(hn, "_cad_fp8", None) if (_FP8_IN_PROJ and hn.is_contiguous()) else None  # (ops.add_norm attaches it)
+    fp8_act = ops.fp8_operand_of(hn) if _FP8_IN_PROJ else None  # (ops.add_norm(want_fp8=True) attaches it; stale copies are refused)
     out = BiMambaMixerFn.apply(hn.reshape(S * B * Lq, Dm), S * B, Lq, split, cache, fp8_act, mamba_fwd.in_proj.weight,
                                mamba_fwd.out_proj.weight, *ps)
     return out.view(S, B, Lq, Dm)

@@ -121,7 +121,7 @@ class RCPSMambaBlock(nn.Module):
     def forward_tframe(self, hidden: Tensor, residual: Optional[Tensor], act: torch.dtype):
         if self.fused_add_norm:
             w, b, eps, is_rms = norm_params(self.norm)
-            hn, residual = ops.add_norm(hidden, residual, w, b, eps, is_rms, True, act)
+            hn, residual = ops.add_norm(hidden, residual, w, b, eps, is_rms, True, act, want_fp8=True)  # (feeds the mixer's in_proj)
         else:
             hn, residual = self.norm.forward_tframe(hidden, residual, act)
         return self.mixer.forward_tframe(hn), residual

@@ -127,19 +127,43 @@ class _AddNorm(torch.autograd.Function):
 
 
 def add_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, bias: Optional[torch.Tensor],
-             eps: float, is_rms: bool, swap_flip: bool, y_dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+             eps: float, is_rms: bool, swap_flip: bool, y_dtype: torch.dtype, want_fp8: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """x: (S, ..., D) t-frame.  Returns (normed in y_dtype, fp32 residual stream) -- rms_norm_fn(prenorm=True) for both
-    strands at once, with the reference's fused-path strand swap as an index map when `swap_flip`."""
+    strands at once, with the reference's fused-path strand swap as an index map when `swap_flip`.
+    want_fp8: the caller feeds `normed` to mixer.bimamba_mixer, whose in_proj runs on the fp8 matrix cores (configs[4]) -- only those
+    call sites ask for the e4m3 epilogue (the final norm_f, the un-fused wrapper and the sequence-parallel path never consume it)."""
     if swap_flip and x.shape[0] != 2:
         raise ValueError("swap_flip needs two strands")
-    if FP8_ACTIVATIONS and y_dtype == torch.bfloat16 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 512 and \
-            bool(L.get_lib().cad_proj_fp8_supported(int(x.shape[-1]))):
-        # configs[4]: the in_proj that consumes this tensor runs on the fp8 matrix cores -- its e4m3 operand (+ per-token scales) is
-        # written by this kernel's epilogue and travels with the tensor (mixer.bimamba_mixer picks it up; anything else ignores it)
+    D = int(x.shape[-1])
+    if want_fp8 and FP8_ACTIVATIONS and y_dtype == torch.bfloat16 and D % 4 == 0 and D <= 512 and _fp8_epilogue_aligned(x, residual) and \
+            bool(L.get_lib().cad_proj_fp8_supported(D)):
+        # its e4m3 operand (+ per-token scales) is written by this kernel's epilogue and travels with the tensor, together with what
+        # identifies the contents it was made from (fp8_operand_of checks version, storage and shape before the mixer trusts it)
         y, res, yq, ys = _AddNorm.apply(x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype, True)
-        y._cad_fp8 = (yq, ys)
+        y._cad_fp8 = (yq, ys, y._version, y.data_ptr(), tuple(y.shape))
         return y, res
     return _AddNorm.apply(x, residual, weight, bias, eps, is_rms, swap_flip, y_dtype)
+
+
+def _fp8_epilogue_aligned(x, residual) -> bool:
+    """cad_add_norm_fwd writes the e4m3 copy from its 16-byte vector instantiation only (addnorm.hip: CAD_ERR_UNSUPPORTED otherwise):
+    mirror that here, so that an input the scalar kernel serves keeps working with the fp8 projection switched on."""
+    ok = x.is_contiguous() and x.data_ptr() % 16 == 0 and (x.shape[-1] * x.element_size()) % 16 == 0
+    if residual is not None:
+        ok = ok and residual.data_ptr() % 16 == 0
+    return ok
+
+
+def fp8_operand_of(y: torch.Tensor):
+    """(e4m3 copy, per-token scales) attached by add_norm(want_fp8=True), or None unless `y` still is the tensor they were made from:
+    same storage, same shape, and not written since (an in-place op between the norm and the mixer bumps the version counter)."""
+    rec = getattr(y, "_cad_fp8", None)
+    if rec is None or not y.is_contiguous():
+        return None
+    yq, ys, ver, ptr, shape = rec
+    if y._version != ver or y.data_ptr() != ptr or tuple(y.shape) != shape:
+        return None
+    return yq, ys
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -194,16 +218,18 @@ def causal_conv1d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
 #   composition of the k maps per row in the row's own direction (a few element-wise launches on (E, SB * k, N) tensors),
 #   pass 2 (the full kernels) from the true entry states (h0 / dhT of the scan C-ABI).
 # The same carries and composition chain segments ACROSS ranks in caduceus_amd/seqpar.py.
-_CU_COUNT = None
+_CU_COUNT = {}
 
 
 def _cu_count() -> int:
-    """Compute units of the current device (256 on MI355X), queried once; 256 without a device (host emulator)."""
-    global _CU_COUNT
-    if _CU_COUNT is None:
-        _CU_COUNT = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) \
-            if torch.cuda.is_available() else 256
-    return _CU_COUNT
+    """Compute units of the CURRENT device (256 on MI355X), queried once per device; 256 without a device (host emulator).  The
+    library's launchers size their grids with the same number (csrc/api.hip: cad_cu_count)."""
+    if not torch.cuda.is_available():
+        return 256
+    dev = torch.cuda.current_device()
+    if dev not in _CU_COUNT:
+        _CU_COUNT[dev] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    return _CU_COUNT[dev]
 
 
 def lsplit_factor(E: int, SB: int, Lq: int, nsets: int) -> int:

@@ -30,6 +30,26 @@ __device__ __forceinline__ float cad_rsqrt(float x) {
     return 1.0f / sqrtf(x);
 }
 
+__device__ __forceinline__ uint32_t cad_perm(uint32_t s0, uint32_t s1, uint32_t sel) {  // v_perm_b32 (selectors 0..7 and 0x0c)
+    uint32_t r = 0;
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t k = (sel >> (8 * b)) & 0xffu;
+        uint32_t byte = 0;
+        if (k < 4)
+            byte = (s1 >> (8 * k)) & 0xffu;
+        else if (k < 8)
+            byte = (s0 >> (8 * (k - 4))) & 0xffu;
+        else if (k >= 13)
+            byte = 0xffu;
+        r |= byte << (8 * b);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float cad_mul_legacy(float a, float b) {  // v_mul_legacy_f32
+    return (a == 0.0f || b == 0.0f) ? 0.0f : a * b;
+}
+
 template <int N>
 __device__ __forceinline__ float dpp_row_shr(float old, float v) {
     const int lane = emu::lane_id();

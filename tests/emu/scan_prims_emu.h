@@ -17,6 +17,26 @@ __device__ __forceinline__ float dot2_acc(float acc, f32x2 a, f32x2 b) {
     return __builtin_fmaf(a[1], b[1], __builtin_fmaf(a[0], b[0], acc));
 }
 
+__device__ __forceinline__ float dot2_first(f32x2 a, f32x2 b) {
+    return __builtin_fmaf(a[1], b[1], a[0] * b[0]);
+}
+
+__device__ __forceinline__ f32x2 group8_sum2_dpp(f32x2 v) {  // butterfly over lane ^ 1, lane ^ 2, then the mirrored lane of the 8-lane half row
+    const int lane = emu::lane_id();
+    for (int c = 0; c < 2; ++c) {
+        float x = v[c];
+        x = emu_exchange(x, lane ^ 1) + x;
+        x = emu_exchange(x, lane ^ 2) + x;
+        x = emu_exchange(x, (lane & ~7) | (7 - (lane & 7))) + x;
+        v[c] = x;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void add_on_lanes_mod8(f32x2& acc, f32x2 x, int k) {
+    if ((emu::lane_id() & 7) == k) acc = acc + x;
+}
+
 __device__ __forceinline__ f32x2 wave_sum2_dpp(f32x2 v) {
     return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1]));
 }

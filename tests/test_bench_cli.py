@@ -39,6 +39,10 @@ def _run(nproc, extra, tmp_path):
 @pytest.mark.parametrize("nproc,extra,accum,scaling", [
     (2, [], 1, "weak"),                        # configs[3]'s launch shape: one sequence per rank and step
     (2, ["--global-batch", "4"], 2, "strong"),  # the reference's fixed global batch: 2 micro-steps per rank, first under no_sync()
+    # configs[3] as the reference runs it on fewer GPUs (hg38.yaml:17: accumulate_grad_batches = 8 / devices): N = 2 -> 4 micro-steps,
+    # N = 4 -> 2, global batch 8 either way
+    (2, ["--global-batch", "8"], 4, "strong"),
+    (4, ["--global-batch", "8"], 2, "strong"),
 ])
 def test_bench_two_ranks_over_gloo(tmp_path, nproc, extra, accum, scaling):
     line = _run(nproc, extra, tmp_path)
@@ -49,6 +53,9 @@ def test_bench_two_ranks_over_gloo(tmp_path, nproc, extra, accum, scaling):
     assert line["scaling"] == scaling and line["higher_is_better"] is True and line["vs_baseline"] is None
     assert line["config"]["parallelism"] == f"dp{nproc}" and line["config"]["accumulate_grad_batches"] == accum
     assert line["config"]["global_batch"] == nproc * accum
+    d = line["dist"]
+    assert d["world_size"] == nproc and d["backend"] == "gloo" and d["buckets"] >= 1 and d["grad_allreduce_bytes_per_step"] > 0
+    assert d["allreduce_exposed_ms_per_step"] is not None and d["allreduce_exposed_ms_per_step"] >= 0.0
     # whole-job aggregate: tokens of ALL ranks and micro-steps over the MAX-over-ranks time
     tokens = 256 * nproc * 2 * accum
     assert abs(line["value"] - tokens / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
@@ -59,3 +66,4 @@ def test_bench_two_ranks_over_gloo(tmp_path, nproc, extra, accum, scaling):
 def test_bench_single_rank_line(tmp_path):
     line = _run(1, [], tmp_path)
     assert line["n_gpus"] == 1 and line["config"]["parallelism"] == "dp1" and line["scaling"] == "weak"
+    assert line["dist"]["world_size"] == 1 and line["dist"]["allreduce_exposed_ms_per_step"] is None

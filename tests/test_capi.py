@@ -112,3 +112,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.get_lib()
     monkeypatch.undo()
     _lib.use_library_for_testing(None)
+
+
+def test_timing_builds_are_fenced(monkeypatch):
+    """A library whose scan kernels were cut down for timing experiments (-DSC_WHATIF / -DSC_TIMING: wrong results by construction, e.g.
+    build()'s libcaduceus_hip_floor.so) names itself in cad_version() and is refused by the loader unless the caller opts in; the
+    product library carries neither marker."""
+    from caduceus_amd import _build
+    _build.build_hip()
+    floor = _build.build_floor()
+    monkeypatch.delenv("CADUCEUS_AMD_ALLOW_TIMING_BUILD", raising=False)
+    with pytest.raises(RuntimeError, match="timing build"):
+        _lib._bind(floor)
+    monkeypatch.setenv("CADUCEUS_AMD_ALLOW_TIMING_BUILD", "1")
+    ver = _lib._bind(floor).cad_version().decode()
+    assert "TIMING-BUILD" in ver and "variant[SC_WHATIF=14434]" in ver, ver
+    monkeypatch.delenv("CADUCEUS_AMD_ALLOW_TIMING_BUILD")
+    ver = _lib._bind(_build.LIB).cad_version().decode()
+    assert "TIMING-BUILD" not in ver and "variant" not in ver, ver

@@ -36,6 +36,60 @@ def test_rcps_embedding(backend):
     assert torch.equal(out, rc_tensor(out_rc))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_rcps_wrapper_generic_submodule(backend, dtype):
+    """test_rcps.py:76-109, restated directly: RCPSWrapper around a GENERIC submodule (the reference's Linear / ReLU stack, which has no
+    t-frame fast path), batch 2 x seqlen 1024 x 2 * 128 channels.  The wrapper's own work is index maps, so the property holds
+    bit-exactly wherever the submodule is row-wise deterministic; the reference's tolerances are the stated bound."""
+    _, dev = backend
+    torch.manual_seed(0)
+    d_model = 128
+    from caduceus_amd import RCPSWrapper
+    x = torch.randn(2, 1024, 2 * d_model, device=dev, dtype=dtype)
+    module = torch.nn.Sequential(torch.nn.Linear(d_model, d_model, bias=False), torch.nn.ReLU(),
+                                 torch.nn.Linear(d_model, 2 * d_model, bias=True), torch.nn.ReLU(),
+                                 torch.nn.Linear(2 * d_model, d_model, bias=True)).to(dev).to(dtype)
+    wrapped = RCPSWrapper(module).to(dev)
+    out, rc_out = wrapped(x), rc_tensor(wrapped(rc_tensor(x)))
+    assert out.shape == x.shape and rc_out.shape == x.shape
+    rtol, atol = (6e-4, 2e-3) if dtype == torch.float32 else (3e-3, 5e-3)  # test_rcps.py:83
+    torch.testing.assert_close(out.detach(), rc_out.detach(), rtol=rtol, atol=atol)
+    assert torch.equal(out, rc_out)  # (the same rows go through the same GEMMs: exact here)
+
+
+@pytest.mark.parametrize("prenorm", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_rcps_add_norm_wrapper_direct(backend, prenorm, dtype):
+    """test_rcps.py:112-146, restated directly: RCPSAddNormWrapper(RMSNorm) on a random (2, 1024, 2 * 128) input, prenorm on / off (the
+    reference runs float16; bf16 / fp32 are the kernels' own instantiations).  One add + norm launch over both strands as rows: exact."""
+    _, dev = backend
+    torch.manual_seed(0)
+    d_model = 128
+    from caduceus_amd import RCPSAddNormWrapper
+    from caduceus_amd.mamba import RMSNorm
+    x = torch.randn(2, 1024, 2 * d_model, device=dev, dtype=dtype)
+    norm = RMSNorm(d_model, eps=1e-5).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(1.0 + 0.1 * torch.randn(d_model))
+    wrapped = RCPSAddNormWrapper(norm).to(dev)
+    out, out_rc = wrapped(x, prenorm=prenorm), wrapped(rc_tensor(x), prenorm=prenorm)
+    pairs = list(zip(out, out_rc)) if prenorm else [(out, out_rc)]
+    assert len(pairs) == (2 if prenorm else 1)
+    for f, r in pairs:
+        assert f.shape == x.shape and r.shape == x.shape
+        assert torch.equal(f, rc_tensor(r))
+    # ... and the values are the un-fused reference computation (modeling_rcps.py:107-130): each strand normed by the same RMSNorm
+    y = pairs[0][0].float()
+    xf = x.float()
+    ref = torch.cat([t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5) * norm.weight.float()
+                     for t in (xf[..., :d_model], xf[..., d_model:])], dim=-1)
+    # (strand 2 is normed in the flipped frame: the weight meets its channels reversed)
+    ref[..., d_model:] = (xf[..., d_model:] * torch.rsqrt(xf[..., d_model:].pow(2).mean(-1, keepdim=True) + 1e-5)
+                          * norm.weight.float().flip(0))
+    rtol, atol = (6e-4, 2e-3) if dtype == torch.float32 else ((3e-3, 5e-3) if dtype == torch.float16 else (3e-2, 5e-2))
+    torch.testing.assert_close(y, ref, rtol=rtol, atol=atol)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("bidirectional", [True, False])

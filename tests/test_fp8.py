@@ -66,15 +66,20 @@ def test_add_norm_writes_the_e4m3_operand_of_the_in_proj(backend, D, swap):
     w = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
     try:
         mixer.set_fp8_in_proj(True)
-        y, r = ops.add_norm(x, res, w, None, 1e-5, True, swap, torch.bfloat16)
+        y, r = ops.add_norm(x, res, w, None, 1e-5, True, swap, torch.bfloat16, want_fp8=True)
+        y1, _ = ops.add_norm(x, res, w, None, 1e-5, True, swap, torch.bfloat16)  # not asked for (final norm, un-fused wrapper): not written
     finally:
         mixer.set_fp8_in_proj(False)
-    y0, r0 = ops.add_norm(x, res, w, None, 1e-5, True, swap, torch.bfloat16)
-    assert torch.equal(y, y0) and torch.equal(r, r0) and not hasattr(y0, "_cad_fp8")
-    yq, ys = y._cad_fp8
+    y0, r0 = ops.add_norm(x, res, w, None, 1e-5, True, swap, torch.bfloat16, want_fp8=True)  # (fp8 projection off: not written either)
+    assert torch.equal(y, y0) and torch.equal(r, r0) and not hasattr(y0, "_cad_fp8") and not hasattr(y1, "_cad_fp8")
+    yq, ys = ops.fp8_operand_of(y)
     q_ref, s_ref = ops.quant_rows_fp8(y.reshape(-1, D))
     assert torch.equal(yq.reshape(-1, D), q_ref) and torch.equal(ys, s_ref)
     assert float(ys.min()) > 0
+    # the copy is tied to the contents it was made from: an in-place write to the bf16 tensor (a hook, in-place dropout) retires it, and
+    # the mixer then quantises the current contents itself
+    y.mul_(2.0)
+    assert ops.fp8_operand_of(y) is None
 
 
 def test_fp8_model_step_takes_the_producer_written_operand(backend, monkeypatch):

@@ -590,3 +590,64 @@ def test_reduce_partials_multi_equals_the_single_folds(backend, dtype, n, npart)
         assert torch.equal(single[i], multi[i])
         torch.testing.assert_close(single[i].float().cpu(), srcs[i].float().sum(0).cpu(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-5,
                                    atol=5e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
+LEAN_CASES = [  # E, SB, L, split, rev_lo, rev_hi -- bf16, d_state 16, L % 8 == 0, delta_is_dt: the production instantiation of the backward
+    (9, 3, 1104, 2, 1, 0),   # two workgroups (the second with 7 padding waves), chunks 512 + 512 + 80 (lanes 10.. of the tail outside)
+    (8, 2, 512, 1, 0, 1),    # exactly one chunk, both directions
+    (16, 1, 8, 1, 1, 1),     # one lane of one chunk
+]
+
+
+@pytest.mark.parametrize("case", LEAN_CASES)
+@pytest.mark.parametrize("nsets", [1, 2])
+def test_scan_backward_lean_production_instantiation(backend, case, nsets):
+    """The unrolled bf16 / d_state 16 / vector-path / delta_is_dt backward (scan_bwd_kernel<bf16, true, false, 8, true>: lean prologue and
+    epilogue -- out-of-row lanes silenced by dt = dy = 0 instead of per-item selects, v_perm unpack, dt taken from the (dt, dt u) pairs,
+    dA summed in 8-lane groups) against the fp32 oracle on the same bf16-rounded inputs: output and EVERY gradient, with a ragged tail
+    chunk, padding waves, both directions, exact-zero gates, one and two parameter sets under a shared gate."""
+    name, dev = backend
+    E, SB, L, split, rl, rh = case
+    N, dtype = 16, torch.bfloat16
+    dirs = [(rl, rh), (1 - rl, 1 - rh)][:nsets]
+    order = ("u", "delta", "A", "B", "C", "D", "bias")
+    act = {"u", "delta", "B", "C"}
+    ts = []
+    for i in range(nsets):
+        t = _scan_inputs(E, SB, L, N, 31 + i, dev, dtype)
+        raw = (0.5 * t["delta"] - 1.0)
+        t["delta"] = torch.nn.functional.softplus(raw + t["bias"][:, None, None]).to(dtype).float()  # dt as the dt_proj epilogue stores it
+        t["delta"][0, 0, : min(L, 24)] = 0.0  # dt == 0 inside the row too (softplus underflow): sigmoid'(..) = 0 there, nothing breaks
+        ts.append(t)
+    z = ts[0]["z"].clone()
+    z[1, 0, 3] = 0.0  # exact-zero gates: the fix-up worklist path
+    z[E - 1, SB - 1, L - 1] = 0.0
+    w = [t["w"] for t in ts]
+    # device run
+    zd = leaf(z, dev, dtype)
+    dsets = [tuple(leaf(t[k], dev, dtype if k in act else torch.float32) for k in order) for t in ts]
+    outs = ops.selective_scan_multi(dsets, zd, split, dirs, delta_is_dt=True)
+    sum((o.float() * w[i].to(dev)).sum() for i, o in enumerate(outs)).backward()
+    # oracle: raw delta = softplus^-1(dt) (so that its softplus returns the very dt the kernel saw), bias 0: d raw = d dt * sigmoid(raw)
+    zr = leaf(z, "cpu")
+    rsets = []
+    for t in ts:
+        tt = dict(t)
+        dtv = t["delta"].double()
+        tt["delta"] = torch.where(dtv > 0, dtv + torch.log(-torch.expm1(-dtv)), torch.full_like(dtv, -200.0)).float()
+        tt["bias"] = torch.zeros_like(t["bias"])
+        rsets.append(tuple(leaf(tt[k], "cpu") for k in order))
+    refs = []
+    for i, (u, d, A, B, C, D, b) in enumerate(rsets):
+        refs.append(_rows_oracle(lambda u_, d_, B_, C_, z_: om.selective_scan(u_, d_, A, B_, C_, D, z_, b), [u, d, B, C, zr],
+                                 split, *dirs[i]))
+    sum((r * w[i]).sum() for i, r in enumerate(refs)).backward()
+    for i in range(nsets):
+        torch.testing.assert_close(outs[i].float().cpu(), refs[i].detach(), **BF16)
+        for k, a, r in zip(order, dsets[i], rsets[i]):
+            scale = max(1.0, float(r.grad.abs().max()))
+            torch.testing.assert_close(a.grad.float().cpu(), r.grad, rtol=BF16["rtol"], atol=BF16["atol"] * scale,
+                                       msg=lambda m, k=k, i=i: f"set {i} d{k}: {m}")
+            assert float((a.grad.float().cpu() - r.grad).norm() / r.grad.norm().clamp_min(1e-12)) < 2e-2, (i, k)
+    scale = max(1.0, float(zr.grad.abs().max()))
+    torch.testing.assert_close(zd.grad.float().cpu(), zr.grad, rtol=BF16["rtol"], atol=BF16["atol"] * scale)

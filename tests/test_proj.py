@@ -306,3 +306,44 @@ def test_mixer_layer_own_streaming_gemms_match_the_library_path(backend, monkeyp
                            torch.zeros(2 * Lq, D, dtype=torch.bfloat16, device=dev)) is not None
     for a, b in zip(res[True], res[False]):
         assert float((a - b).norm() / b.norm()) < 5e-3
+
+
+@pytest.mark.parametrize("Lq", [1104, 512])
+def test_mixer_layer_bf16_production_scans_against_the_generic_fp32_path(backend, monkeypatch, Lq):
+    """One weight-tied BiMamba mixer layer (d_model 128: E = 256, dt_rank 8, d_state 16; both strands; chunks 512 + 512 + 80 with
+    out-of-row lanes in the tail) through the hand-scheduled bf16 path -- dt from the dt_proj epilogue, so the backward scan is the lean
+    production instantiation with the SHARED gate gradient (out2) -- against the same layer on the generic per-op autograd path in fp32
+    (engine._bimamba_tframe: the generic kernel instantiations, which tests/test_kernels.py holds to the oracle): output, input gradient and
+    every parameter gradient by relative error norm, at the bf16 class."""
+    from caduceus_amd import engine, mixer
+    from caduceus_amd.mamba import Mamba
+    name, dev = backend
+    torch.manual_seed(7)
+    D = 128
+    mf, mr = Mamba(D, device=dev), Mamba(D, device=dev)
+    mr.in_proj.weight = mf.in_proj.weight
+    mr.out_proj.weight = mf.out_proj.weight
+    hn0 = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    g = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    params = {tag + "." + k: v for m, tag in ((mf, "f"), (mr, "r")) for k, v in m.named_parameters()}
+
+    def run(fast):
+        for p in params.values():
+            p.grad = None
+        hn = (hn0 if fast else hn0.float()).clone().requires_grad_(True)
+        if fast:
+            assert mixer.can_use(mf, mr, "add") and ops.proj_wx_supported(hn0, mf.dt_rank, 2 * Lq)  # fused softplus -> delta_is_dt
+            out = mixer.bimamba_mixer(hn, mf, mr, 1)
+        else:
+            monkeypatch.setattr(mixer, "can_use", lambda *a, **k: False)
+            out = engine._bimamba_tframe(hn, mf, mr, "add", True)
+            monkeypatch.undo()
+        out.backward(g if fast else g.float())
+        res = {k: p.grad.detach().float().cpu().clone() for k, p in params.items()}
+        res["out"], res["x"] = out.detach().float().cpu(), hn.grad.float().cpu()
+        return res
+
+    fast, ref = run(True), run(False)
+    for k in ref:
+        rel = float((fast[k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-20))
+        assert rel < 3e-2, (k, rel)

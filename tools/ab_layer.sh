@@ -4,6 +4,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 rounds=$1; shift
+export CADUCEUS_AMD_ALLOW_TIMING_BUILD=1   # what-if variants (-DSC_WHATIF) are timing builds: the loader refuses them otherwise
 : > gpurun_out/ab_layer.log
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
