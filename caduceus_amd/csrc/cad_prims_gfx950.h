@@ -43,11 +43,13 @@ __device__ __forceinline__ uint32_t cad_perm(uint32_t s0, uint32_t s1, uint32_t 
     return __builtin_amdgcn_perm(s0, s1, sel);
 }
 
-// v_mul_legacy_f32: a product in which 0 * anything (inf, NaN) is 0
+// v_mul_legacy_f32: a product in which 0 * anything (inf, NaN) is 0.  Through the LLVM intrinsic (this clang has no builtin for it), NOT
+// inline asm: the operand is usually the result of a transcendental (v_rcp_f32), and a VALU read of a transcendental's result needs a
+// wait state that the compiler's hazard recognizer only inserts for instructions it can see -- the asm form read stale registers on
+// the device (round 5: dz of the first item of ~10 % of the lanes was 0; the host emulator cannot show this class of error).
+extern "C" __device__ float cad_llvm_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
 __device__ __forceinline__ float cad_mul_legacy(float a, float b) {
-    float r;
-    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return cad_llvm_fmul_legacy(a, b);
 }
 
 // ---- cross-lane primitives (DPP on gfx950; emulated through the fiber exchange in the test build) -----------------

@@ -184,17 +184,16 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) dt[i] = cad_softplus(dt[i] + bias);
         }
+        float csum = 0.f;  // sum of dt over the lane's items: the product of the lane's a_i is exp2(A2 * csum)
 #pragma unroll
         for (int i = 0; i < SC_S; ++i) {
             const float sp = dt[i];
             const float dti = (VEC ? (p0 < L) : (p0 + i < L)) ? sp : 0.f;
             y2[i] = f2(Dv * du[i], 0.f);
             dd[i] = f2(dti, dti * du[i]);
+            csum += dti;
         }
-        if (a.sum_dt) {  // wave-uniform; only the sequence-parallel / segmented callers ask for it
-#pragma unroll
-            for (int i = 0; i < SC_S; ++i) sdt += dd[i][0];
-        }
+        if (a.sum_dt) sdt += csum;  // wave-uniform; only the sequence-parallel / segmented callers ask for it
         // running state at this chunk's start (first slot of the chunk); a mid-chunk state (second slot) is written per pair
         float* st_base = (a.chunk_state && !MO) ? a.chunk_state + (((int64_t)e * SB + sb) * nslots + SLOTS * c) * NP * 2 : nullptr;
         if (st_base && act && lane < NP) {
@@ -221,27 +220,28 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
             const f32x2 A2 = readlane2(Areg, np);
-            // (i) serial scan over the lane's items
-            f32x2 acc_a = f2(1.f), acc_h = f2(0.f);
-            f32x2 ha[SC_S], hh[SC_S];
+            // (i) serial scan over the lane's items: the lane's map is (prod a_i, acc_h); the a_i / b_i are kept for the second pass
+            // (round 5: the true states are then ONE dependent v_pk_fma per item from the state entering the lane -- the earlier form
+            // kept the cumulative maps (ha, hh) instead, one more v_pk_mul per item for the running product of the a_i)
+            f32x2 acc_h = f2(0.f);
+            f32x2 ha[SC_S], hh[SC_S];  // a_i, b_i
+            const f32x2 acc_a = exp2_2(f2(csum) * A2);
 #pragma unroll
             for (int i = 0; i < SC_S; ++i) {
                 const f32x2 av = (SC_WHATIF & 128) ? splat_lo(dd[i]) * A2 : exp2_2(splat_lo(dd[i]) * A2);
                 const f32x2 bv = splat_hi(dd[i]) * ((SC_WHATIF & 64) ? f2(__builtin_bit_cast(float, lane + i)) : ld2(tB + 2 * i));
                 acc_h = av * acc_h + bv;
-                acc_a = acc_a * av;
-                ha[i] = acc_a;
-                hh[i] = acc_h;
+                ha[i] = av;
+                hh[i] = bv;
             }
             SC_TIME(2);  // staging issue + exp + serial scan (B tile reads)
-            // (ii) inclusive scan of the affine maps across lanes (DPP)
-            f32x2 PA = acc_a, PH = acc_h;
-            if (!(SC_WHATIF & 512)) wave_scan_fwd(PA, PH);
-            const f32x2 ea = f2(dpp_wave_shr1(1.f, PA[0]), dpp_wave_shr1(1.f, PA[1]));
-            const f32x2 eh = f2(dpp_wave_shr1(0.f, PH[0]), dpp_wave_shr1(0.f, PH[1]));
-            // (iii) carry in / out  (folding the carry into lane 0 before the scan, as the backward does, measured +0.8 % here)
+            // (ii) inclusive scan of the affine maps across lanes (DPP), the state entering the chunk folded into lane 0's map: PH is
+            // the TRUE state leaving every lane, the map products are dead afterwards
             const f32x2 hin = readlane2(carry, np);
-            const f32x2 h0 = ea * hin + eh;
+            f32x2 PH = acc_h;
+            if (!(SC_WHATIF & 512)) wave_scan_fwd_carry(acc_a, PH, hin, lane);
+            // (iii) state entering this lane's segment / carry out
+            const f32x2 h0 = f2(dpp_wave_shr1(hin[0], PH[0]), dpp_wave_shr1(hin[1], PH[1]));
             // state entering lane 32 = state at logical position base + 512: the backward's half-chunk start
             if (SLOTS == 2 && st_base && act && base + SC_STATE_STEP < L) {
                 const f32x2 mid = readlane2(h0, SC_STATE_STEP / SC_S);
@@ -250,17 +250,20 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
                     st_base[(NP + np) * 2 + 1] = mid[1];
                 }
             }
-            const f32x2 newc = readlane2(PA * hin + PH, 63);
+            const f32x2 newc = readlane2(PH, 63);
             if (lane == np) carry = newc;
             SC_TIME(3);  // wave scan + carry
             cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
             if constexpr (!MO) {
+            f32x2 h = h0;
 #pragma unroll
-            for (int i = 0; i < SC_S; i += 2) {  // two items per step: h of the second separates h of the first from its use
-                const f32x2 hA = ha[i] * h0 + hh[i], hB = ha[i + 1] * h0 + hh[i + 1];
+            for (int i = 0; i < SC_S; i += 2) {  // two items per step (one 16-byte C read); the output FMA of item i sits between the
+                                                 // dependent state updates of items i and i + 1
+                const f32x2 hA = ha[i] * h + hh[i];
                 const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]} : *(const f32x4*)(tC + 2 * i);
+                h = ha[i + 1] * hA + hh[i + 1];
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
-                pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), hB);
+                pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), h);
             }
             }
             SC_TIME(4);  // output phase (C tile reads)
