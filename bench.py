@@ -185,6 +185,11 @@ def cpu_baseline_worker(scan_L=131072, reps_model=15, reps_scan=3):
 INSTR_PRICE_NS = {"scan_fwd": 0.477, "scan_bwd": 0.977}
 
 
+# counter profile of the two scan kernels at the headline launch shape (tools/prof_scan.sh + tools/make_scan_pmc_json.py), stamped with
+# the library and scan-source hashes it was taken on; quoted in `roofline` only while pmc_quotable() holds
+SCAN_PMC_FILE = os.path.join("profiles", "r05_scan_pmc.json")
+
+
 def pmc_quotable(pmc: dict, lib_version: str):
     """A committed counter profile of the scans may be quoted next to a timing of THIS library when it was taken on this very build,
     or on a build whose SCAN sources (scan_*.hip, scan_common.h, cad_common.h, the C-ABI header: `_build.scan_source_hash`) are the
@@ -424,17 +429,17 @@ def main():
         # ... and only when the profile was taken on THIS build of the kernels (cad_version() carries a hash of the sources)
         traffic, traffic_note = None, "no counter profile for this launch shape"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_scan_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, SCAN_PMC_FILE)))
             sh = pmc["shape"]
             if dom and (sh["E"], sh["L"], sh["N"], sh["dtype"]) == (E, args.seqlen, N, args.dtype) and \
                     sh["rows"] == (2 if args.model == "ps" else 1) * args.batch:
                 why = pmc_quotable(pmc, _lib.version())
                 if why:
                     traffic = pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"]
-                    traffic_note = ("HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
-                                    "profiles/r04_scan_pmc.json taken on " + why)
+                    traffic_note = ("HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, " +
+                                    SCAN_PMC_FILE + " taken on " + why)
                 else:
-                    traffic_note = (f"profiles/r04_scan_pmc.json was taken on another build ({pmc.get('lib_version')}); this "
+                    traffic_note = (f"{SCAN_PMC_FILE} was taken on another build ({pmc.get('lib_version')}); this "
                                     f"library is {_lib.version()}: not quoted")
         except (OSError, KeyError, ValueError):
             traffic = None

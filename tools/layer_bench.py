@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--ab", default=None, help="mixer module switch (e.g. _OWN_DWX) to toggle IN THIS PROCESS: blocks of --reps "
                     "layers alternate on / off for --rounds rounds, so both arms see the same clocks and power state")
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--tag", default=None, help="label of this run in the output (tools/ab_layer.sh: the variant name)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -75,7 +76,7 @@ def main():
     torch.cuda.synchronize()
     pr = _lib.prof_read()
     _lib.prof_enable(False)
-    res = {"lib": os.environ.get("CADUCEUS_AMD_LIB", "default"), "layer_ms": round(e0.elapsed_time(e1) / a.reps, 3)}
+    res = {"lib": a.tag or os.environ.get("CADUCEUS_AMD_LIB", "default"), "layer_ms": round(e0.elapsed_time(e1) / a.reps, 3)}
     for k, (ms, n) in pr.items():
         if n:
             res[k + "_ms"] = round(ms / n, 4)

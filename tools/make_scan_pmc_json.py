@@ -1,5 +1,5 @@
 """GPU box, after tools/prof_scan.sh: condenses the rocprofv3 counter CSVs of the scan micro-benchmark into the JSON that bench.py
-quotes as `roofline.traffic` (profiles/r04_scan_pmc.json), stamped with cad_version() of the library that was profiled.
+quotes as `roofline.traffic` (bench.SCAN_PMC_FILE), stamped with cad_version() of the library that was profiled.
 Per-dispatch averages of the two-set production launches only (selected by their grid size); FETCH_SIZE x 2 and the KiB unit
 per the gfx950 notes of MI355X_MICROARCH.md."""
 import csv
