@@ -76,7 +76,7 @@ class ScanArgs(C.Structure):
     _fields_ = [("u", _p), ("delta", _p), ("A", _p), ("Bm", _p), ("Cm", _p), ("D", _p), ("z", _p),
                 ("delta_bias", _p), ("out", _p), ("chunk_state", _p), ("SB", _i64), ("L", _i64), ("split", _i64),
                 ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i), ("h0", _p), ("hT", _p),
-                ("sum_dt", _p), ("delta_is_dt", _i), ("map_only", _i), ("lane_state", _p)]
+                ("sum_dt", _p), ("delta_is_dt", _i), ("map_only", _i)]
 
 
 class ScanBwdArgs(C.Structure):
@@ -85,7 +85,7 @@ class ScanBwdArgs(C.Structure):
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
                 ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p), ("gate_fix_list", _p), ("gate_fix_count", _p),
-                ("gate_fix_dz", _p), ("delta_is_dt", _i), ("carry_only", _i), ("lane_state", _p)]
+                ("gate_fix_dz", _p), ("delta_is_dt", _i), ("carry_only", _i)]
 
 
 class MlmArgs(C.Structure):
@@ -137,7 +137,6 @@ SYMBOLS = {
     "cad_scan_fwd": (_i, [C.POINTER(ScanArgs), _p]),
     "cad_scan_chunk_len": (_i64, []),
     "cad_scan_state_floats": (_i64, [_i, _i64, _i64, _i]),
-    "cad_scan_lane_state_bytes": (_i64, [_i, _i64, _i64, _i, _i]),
     "cad_scan_bwd": (_i, [C.POINTER(ScanBwdArgs), _p]),
     "cad_scan_fwd_multi": (_i, [C.POINTER(ScanArgs), _i, _p]),
     "cad_scan_bwd_multi": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),

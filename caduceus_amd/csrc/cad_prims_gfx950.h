@@ -131,15 +131,6 @@ __device__ __forceinline__ void cad_glds16(const void* gsrc /* per lane */, uint
                  : "memory");
 }
 
-// ... the 4-byte form (global_load_lds_dword: lane l's dword lands at base + 4 l): 256-byte rows of per-lane words
-__device__ __forceinline__ void cad_glds4(const void* gsrc /* per lane */, uint32_t lds_base /* wave-uniform, SGPR */) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base)
-                 : "memory");
-}
-
 // Point at which every lane of the wave has executed what precedes it.  The hardware runs a wave in lock-step and its LDS
 // queue is in order, so this is only a compiler fence on the device; the host emulator runs lanes as separate fibers and
 // needs a real rendezvous wherever a lane reads LDS written by ANOTHER lane of its wave without a workgroup barrier.

@@ -63,8 +63,6 @@ struct ScanBwdSets {
 #endif
 #define PRE_SLOT (SC_W * 64 * 16)       // bytes per vector slot (all waves)
 #define PRE_BYTES (SC_NDMA * PRE_SLOT)
-#define LS_SLOT (SC_W * 64 * 4)         // bytes per lane-state row slot (all waves): one dword per lane
-#define LS_BYTES (SC_NDMA_LS * LS_SLOT)
 #ifndef SC_SLAB_BUFS
 #define SC_SLAB_BUFS 2                  // 2: one barrier per pair; 1: half the LDS (two workgroups per CU), two barriers
 #endif
@@ -86,9 +84,6 @@ static_assert(SC_S_BWD == 8, "the backward scan is written for 8 items per lane 
 #endif
 #ifndef SC_BWD_LEAN
 #define SC_BWD_LEAN 1   // 0: the round-4 prologue / epilogue / per-pair-step dA wave sum for every launch (A/B switch)
-#endif
-#ifndef SC_BWD_LANE_STATES
-#define SC_BWD_LANE_STATES 1   // 0: ignore cad_scan_bwd_args.lane_state, recompute the running states (A/B switch)
 #endif
 static_assert(SC_W == 4 || SC_W == 8, "staging needs >= 256 threads; the flush mapping is written for 256 / 512");
 
@@ -117,10 +112,7 @@ __device__ __forceinline__ float sc_sigmoid_from_dt(float dt) {
 // per-item select), direction + widening of an item is one v_perm_b32, dt comes from the (dt, dt u) pairs (the raw delta vector is dead
 // after the prologue), the accumulators start from the first pair's products instead of zeros, and dA is summed inside 8-lane groups per
 // pair-step and across the groups once per kernel.  Static count of a 512-position chunk: see profiles/r05_scan_isa_mix.txt.
-// LS = the forward left the state ENTERING every lane segment (cad_scan_bwd_args.lane_state, bf16 pairs): the lean instantiation then
-// starts every lane's recompute from its own state -- no serial pre-pass, no forward wave scan, no chunk-state loads; the eight 256-byte
-// rows of a chunk (one per state pair) travel by LDS-DMA one chunk ahead, behind the item vectors.
-template <typename T, bool VEC, bool CO, int NPC = 0, bool ISDT = false, bool LS = false>
+template <typename T, bool VEC, bool CO, int NPC = 0, bool ISDT = false>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][wave][dB,dC][ACC_TILE] contributions
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
@@ -136,12 +128,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     char* pre = CO ? (char*)acc : (char*)(accp + 2 * PK_BUF);
     constexpr bool LEAN = PREF && ISDT && !CO && NPC != 0;
     static_assert(!ISDT || LEAN, "ISDT is the production instantiation's switch");
-    static_assert(!LS || LEAN, "lane states are read by the lean instantiation only");
-    // LDS-DMA operations a pair-step issues BEHIND its tile loads (the counted staging wait keeps exactly them in flight): the next
-    // chunk's item vectors in pair-step 0, and -- with lane states -- one row of the next chunk in every pair-step
-    constexpr int NDMA = LS ? SC_NDMA + 1 : SC_NDMA, NDMA_LO = LS ? 1 : 0;
-    static_assert(!LS || NPC == SC_NDMA_LS, "one lane-state row per state pair");
-    char* ls_pre = pre + PRE_BYTES;  // [pair][wave][lane] dwords
     const int lane = threadIdx.x & 63;
     // selection matrix of the MFMA flush (see PK_TILE): row i = lane & 15 picks element pi(i & 7) of every piece
     u32x4 selA = {0u, 0u, 0u, 0u};
@@ -206,9 +192,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     // LDS-DMA of the item vectors of the chunk whose lane segment starts at logical position pq.  Always SC_NDMA
     // operations (absent tensors re-fetch u into their slot) so that the counted wait of the staging path is exact.
     const uint32_t pre_lds = cad_uniform((int)(sc_lds_off(pre) + wave * (64 * 16)));
-    const uint32_t ls_lds = cad_uniform((int)(sc_lds_off(ls_pre) + wave * (64 * 4)));
-    const int64_t ls_nseg = L / SC_S;
-    const uint32_t* ls_row = LS ? (const uint32_t*)a.lane_state + ((int64_t)e * SB + sb) * NP * ls_nseg : nullptr;
     auto prefetch_vectors = [&](int64_t pq) {
         const int64_t l0 = pq < L ? (rev ? (L - pq - SC_S) : pq) : 0;  // clamped: out-of-range segments are zeroed at use
         sc_glds16(u_row + l0, pre_lds);
@@ -218,17 +201,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         sc_glds16((o_row ? o_row : u_row) + l0, pre_lds + 4 * PRE_SLOT);
         sc_glds16((o2_row ? o2_row : u_row) + l0, pre_lds + 5 * PRE_SLOT);
     };
-    // the state entering this lane's segment of the chunk at lane position pq, for state pair q: one dword (both states) per lane, by
-    // DMA into row q of the wave's lane-state slots.  Logical segment index -- the forward wrote it in the row's own direction.  A lane
-    // outside the row takes segment 0 (finite; its dt = dy = 0 silence it).
-    auto prefetch_lane_state = [&](int q, int64_t pq) {
-        cad_glds4(ls_row + (int64_t)q * ls_nseg + (pq < L ? pq / SC_S : 0), ls_lds + q * LS_SLOT);
-    };
     if constexpr (PREF) prefetch_vectors((nchunks - 1) * SC_CHUNK + (int64_t)lane * SC_S);
-    if constexpr (LS) {
-#pragma unroll
-        for (int q = 0; q < SC_NDMA_LS; ++q) prefetch_lane_state(q, (nchunks - 1) * SC_CHUNK + (int64_t)lane * SC_S);
-    }
 
     // lane np holds (A[2np], A[2np+1]); broadcast per pair with v_readlane (no memory access in the pair loop)
     f32x2 Areg = f2(0.f);
@@ -242,7 +215,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         carryG = f2(gp[0], (2 * lane + 1 < N) ? gp[1] : 0.f);
     }
     f32x2 hin_next = f2(0.f);
-    if (!CO && !LS && lane < NP) {
+    if (!CO && lane < NP) {
         const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + nchunks - 1) * NP + lane) * 2;
         hin_next = f2(stp[0], stp[1]);
     }
@@ -427,7 +400,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         // running states of all pairs at this chunk's start (saved by the forward): lane np holds pair np; the next
         // (earlier) chunk's states are fetched now and land while this chunk computes
         const f32x2 hin_reg = hin_next;
-        if (!CO && !LS && lane < NP && c > 0) {
+        if (!CO && lane < NP && c > 0) {
             const float* stp = a.chunk_state + ((((int64_t)e * SB + sb) * nchunks + c - 1) * NP + lane) * 2;
             hin_next = f2(stp[0], stp[1]);
         }
@@ -550,21 +523,12 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             for (int i = 0; i < SC_S; ++i) {
                 av[i] = (SC_WHATIF & 128) ? splat_lo(dd[i]) * A2 : exp2_2(splat_lo(dd[i]) * A2);
                 hs[i] = splat_hi(dd[i]) * Bw[i];  // b_i
-                if constexpr (!LS) acc_h = av[i] * acc_h + hs[i];
+                acc_h = av[i] * acc_h + hs[i];
             }
             SC_TIME(3);  // exp + serial scan
-            f32x2 h0;  // state entering this lane's segment
-            if constexpr (LS) {
-                // ... as the forward left it (bf16 pair): one LDS read + two widening shifts instead of 8 FMAs + a 22-step wave scan
-                // (row np of THIS chunk was fetched during the previous chunk's pair-step np and is complete since the chunk-start
-                // wait; once read, the same slot receives the next chunk's row: eight pair-steps of lead, no second buffer)
-                const uint32_t w = *(const uint32_t*)(ls_pre + np * LS_SLOT + wave * (64 * 4) + lane * 4);
-                h0 = f2(cad_bits2f(w << 16), cad_bits2f(w & 0xffff0000u));
-            } else {
-                f32x2 PH = acc_h;
-                if (!(SC_WHATIF & 512)) wave_scan_fwd_carry(acc_a, PH, hin, lane);  // PH: the true state leaving each lane
-                h0 = f2(dpp_wave_shr1(hin[0], PH[0]), dpp_wave_shr1(hin[1], PH[1]));
-            }
+            f32x2 PH = acc_h;
+            if (!(SC_WHATIF & 512)) wave_scan_fwd_carry(acc_a, PH, hin, lane);  // PH: the true state leaving each lane
+            const f32x2 h0 = f2(dpp_wave_shr1(hin[0], PH[0]), dpp_wave_shr1(hin[1], PH[1]));  // state entering this lane's segment
             // the true h_i (forward chain) and 2. the reverse scan of G (backward chain), interleaved: two independent
             // serial v_pk_fma chains, each step of one fills the wait state the other needs between dependent packed ops
             SC_TIME(4);  // forward wave scan
@@ -578,9 +542,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                     RG = av[r] * (Cv[r] * SC_DY(r) + RG);
                     hs[i] = h;  // h_i
                 }
-            }
-            if constexpr (LS) {
-                if (c > 0) prefetch_lane_state(np, p0 - SC_CHUNK);  // (behind this pair-step's tile loads and the read of the row above)
             }
             SC_TIME(5);  // true h + lane-local reverse scan
             f32x2 QG = RG;
@@ -645,7 +606,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             }
             }  // !CO
             SC_TIME(8);  // dA wave sum (+ chunk epilogue on the last pair)
-            if (more) sc_stage_store<T, SC_S, VEC, NDMA, NDMA_LO>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now, LS && c > 0);
+            if (more) sc_stage_store<T, SC_S, VEC>(st, smem + (buf ^ 1) * 2 * TILE, rev, dma_now);
             SC_TIME(9);  // staging store (waits for the tile loads)
             if (!(SC_WHATIF & 2)) __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             SC_TIME(10);  // barrier wait
@@ -979,22 +940,12 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
     bool all_dt = true;  // every set hands over dt itself: the lean production instantiation (ISDT)
     for (int i = 0; i < nsets; ++i) all_dt = all_dt && sets[i].delta_is_dt != 0;
-    // every set brings the lane states its forward wrote (only the shapes cad_scan_lane_state_bytes() admits, i.e. the ones the forward's
-    // production instantiation serves: L % 16 == 0 in particular -- the backward's own vector path would accept L % 8 == 0)
-    bool all_ls = SC_BWD_LANE_STATES != 0;
-    for (int i = 0; i < nsets; ++i)
-        all_ls = all_ls && sets[i].lane_state != nullptr && ((uintptr_t)sets[i].lane_state % 16) == 0 &&
-                 cad_scan_lane_state_bytes(sets[i].E, sets[i].SB, sets[i].L, sets[i].N, sets[i].dtype) > 0;
     const size_t slab_floats = a->carry_only ? 0 : (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF);
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + slab_floats) * sizeof(float) +
                          (pref ? PRE_BYTES : 0);
 #define SC_BWD_LAUNCH(T, V)                                                                  \
     do {                                                                                     \
-        if (SC_BWD_UNROLL_NP && SC_BWD_LEAN && !a->carry_only && V && sizeof(T) == 2 && pref && all_dt && all_ls &&   \
-            a->N == 2 * SC_BWD_UNROLL_NP) {                                                  \
-            SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2, V && sizeof(T) == 2>), shmem + LS_BYTES);             \
-            CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2, V && sizeof(T) == 2>), grid, block, shmem + LS_BYTES, stream, ks); \
-        } else if (SC_BWD_UNROLL_NP && SC_BWD_LEAN && !a->carry_only && V && sizeof(T) == 2 && pref && all_dt &&   \
+        if (SC_BWD_UNROLL_NP && SC_BWD_LEAN && !a->carry_only && V && sizeof(T) == 2 && pref && all_dt &&   \
             a->N == 2 * SC_BWD_UNROLL_NP) {                                                  \
             SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2>), shmem);             \
             CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2>), grid, block, shmem, stream, ks); \

@@ -343,8 +343,8 @@ struct StageRegs {
 // counted form of the wait above: returns as soon as at most `keep` vector-memory operations are outstanding.  Used in
 // the pair-step in which the LDS-DMA prefetch of the next chunk's item vectors (sc_glds16, SC_NDMA operations) was issued
 // BEHIND the tile loads: the tile loads are waited for, the prefetch stays in flight.
-#define SC_NDMA 6        // the item vectors of a chunk
-#define SC_NDMA_LS 8     // lane-state rows of a chunk, one per state pair (backward, cad_scan_bwd_args.lane_state): ONE per pair-step
+#define SC_NDMA 6
+static_assert(SC_NDMA == 6, "the immediate of s_waitcnt vmcnt(6) above");
 
 // ---- LDS-DMA prefetch of the per-chunk item vectors -------------------------------------------------------------------
 // The u / delta / z / dout / out vectors of a chunk are needed at its very start; loaded there they expose the full HBM
@@ -439,15 +439,15 @@ __device__ __forceinline__ void sc_stage_load(StageRegs<T, SC_SV(S)>& r, const S
     }
 }
 
-template <typename T, int S, bool VEC, int NDMA = SC_NDMA, int NDMA_LO = 0>
+template <typename T, int S, bool VEC>
 __device__ __forceinline__ void sc_stage_store(StageRegs<T, SC_SV(S)>& r, float* tiles /* B tile, C tile follows */,
-                                               int rev, bool keep_dma = false, bool keep_lo = false) {
+                                               int rev, bool keep_dma = false) {
     constexpr int SV = SC_SV(S);
     const int t = threadIdx.x;
     if (t >= 256) return;
     if constexpr (VEC) {
         if constexpr (sizeof(StVec<T, SV>) <= 16)
-            sc_async_wait_keep<NDMA, NDMA_LO>(r.s0, r.s1, keep_dma, keep_lo);
+            sc_async_wait_keep(r.s0, r.s1, keep_dma);
         else
             sc_async_wait(r.s0, r.s1);
     }

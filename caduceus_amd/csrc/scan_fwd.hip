@@ -70,13 +70,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
     const int64_t nchunks = (L + SC_CHUNK - 1) / SC_CHUNK;
     const int64_t nslots = (L + SC_STATE_STEP - 1) / SC_STATE_STEP;
     constexpr bool PREF = SC_FWD_DMA && VEC && SC_S * sizeof(T) == 32;
-    // lane states for the bf16 backward (cad_scan_args.lane_state): the state entering every 8-position segment, i.e. entering this
-    // lane's 16 items and after its first 8 -- both exist in registers anyway (wave scan / second pass); one 8-byte store per lane and
-    // pair-step, 512 contiguous bytes per wave.  Written by the unrolled production instantiation only (the launcher checks the shape).
-    constexpr bool LSW = NPC != 0 && !MO && VEC && sizeof(T) == 2 && SC_S == 16;
-    const int64_t ls_nseg = L / 8;
-    uint32_t* ls_lane = (LSW && a.lane_state)
-                            ? (uint32_t*)a.lane_state + ((int64_t)e * SB + sb) * NP * ls_nseg + 2 * lane : nullptr;
     char* pre = (char*)(smem + RING * 2 * TILE);  // behind the tile ring
     const uint32_t pre_lds = cad_uniform((int)(sc_lds_off(pre) + wave * (64 * 16)));
     // SC_NDMA (= 6) DMA operations per chunk: u, delta, z (u again when there is no gate) x two 16-byte planes
@@ -227,7 +220,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             const float* tB = smem + buf * 2 * TILE + lane * ROW;
             const float* tC = tB + TILE;
             const f32x2 A2 = readlane2(Areg, np);
-            u32x2 ls_w = {0u, 0u};
             // (i) serial scan over the lane's items: the lane's map is (prod a_i, acc_h); the a_i / b_i are kept for the second pass
             // (round 5: the true states are then ONE dependent v_pk_fma per item from the state entering the lane -- the earlier form
             // kept the cumulative maps (ha, hh) instead, one more v_pk_mul per item for the running product of the a_i)
@@ -264,18 +256,15 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
             cad_sched_fence();  // do not hoist the C-tile reads above the wave scan (register pressure)
             if constexpr (!MO) {
             f32x2 h = h0;
-            f32x2 hmid = h0;  // state after the lane's first 8 items
 #pragma unroll
             for (int i = 0; i < SC_S; i += 2) {  // two items per step (one 16-byte C read); the output FMA of item i sits between the
                                                  // dependent state updates of items i and i + 1
                 const f32x2 hA = ha[i] * h + hh[i];
                 const f32x4 c4 = (SC_WHATIF & 64) ? f32x4{ha[i][0], ha[i][1], hh[i][0], hh[i][1]} : *(const f32x4*)(tC + 2 * i);
                 h = ha[i + 1] * hA + hh[i + 1];
-                if (i == 6) hmid = h;
                 pk_fma_acc(y2[i], f2(c4[0], c4[1]), hA);
                 pk_fma_acc(y2[i + 1], f2(c4[2], c4[3]), h);
             }
-            if constexpr (LSW) ls_w = u32x2{cad_pack_bf16x2(h0[0], h0[1]), cad_pack_bf16x2(hmid[0], hmid[1])};
             }
             SC_TIME(4);  // output phase (C tile reads)
             if (more) {
@@ -283,12 +272,6 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC_FWD) void scan_fwd_kernel(ScanFwd
                 SC_FWD_ADVANCE();
             }
             SC_TIME(5);  // staging store
-            if constexpr (LSW) {
-                // (behind the staging wait: the tile loads of THIS pair-step were waited for with vmcnt(0) -- a store issued in front of
-                // that wait would put its write acknowledgement on the staging waves' critical path; here it has a whole pair-step)
-                if (ls_lane && act && p0 < L && !(SC_WHATIF & 2048))  // (wave-uniform pointer test; a lane's 16 items are inside the row or not)
-                    *(u32x2*)(ls_lane + (int64_t)np * ls_nseg + base / 8) = ls_w;
-            }
             if ((((NPC ? np : tix) + 1) & (AHEAD - 1)) == 0 && !(SC_WHATIF & 2)) __syncthreads();
             SC_TIME(6);  // barrier
         }
@@ -336,20 +319,11 @@ extern "C" int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N) {
     return (int64_t)E * SB * (nslots + 1) * ((N + 1) / 2) * 2;
 }
 
-extern "C" int64_t cad_scan_lane_state_bytes(int E, int64_t SB, int64_t L, int N, int dtype) {
-    // what the unrolled production instantiations serve: bf16, d_state 16, whole 16-item lane segments (the pointer alignment of the
-    // vector path is the launchers' business: with unaligned operands neither kernel touches the buffer)
-    if (dtype != CAD_BF16 || N != 2 * SC_FWD_UNROLL_NP || SC_FWD_UNROLL_NP == 0 || L <= 0 || (L % SC_S_FWD) != 0 || E <= 0 || SB <= 0) return 0;
-    return (int64_t)E * SB * ((N + 1) / 2) * (L / 8) * 4;
-}
-
 extern "C" int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream) {
     CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= SC_MAXSETS);
     ScanFwdSets ks;
     for (int i = 0; i < nsets; ++i) {
         const cad_scan_args* a = &sets[i];
-        CAD_CHECK_ARG(a->lane_state == nullptr ||
-                      (!a->map_only && cad_scan_lane_state_bytes(a->E, a->SB, a->L, a->N, a->dtype) > 0 && ((uintptr_t)a->lane_state % 16) == 0));
         CAD_CHECK_ARG(a->u && a->delta && a->A && a->Bm && a->Cm && (a->out || a->map_only));
         CAD_CHECK_ARG(!a->map_only || (a->hT && a->sum_dt));
         CAD_CHECK_ARG(a->map_only == sets[0].map_only);

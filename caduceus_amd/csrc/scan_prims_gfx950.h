@@ -302,32 +302,25 @@ __device__ __forceinline__ void sc_async_wait(V& a, V& b) {
     }
 }
 
-template <int KEEP, int KEEP_LO, typename V>
-__device__ __forceinline__ void sc_async_wait_keep(V& a, V& b, bool keep_dma, bool keep_lo) {
+template <typename V>
+__device__ __forceinline__ void sc_async_wait_keep(V& a, V& b, bool keep_dma) {
     static_assert(sizeof(V) == 8 || sizeof(V) == 16, "vector sizes of the prefetching kernels");
     typedef uint32_t uw __attribute__((ext_vector_type(sizeof(V) / 4)));
     uw x = __builtin_bit_cast(uw, a), y = __builtin_bit_cast(uw, b);
     // ONE statement (the scalar branch on the wave-uniform flag is inside it): with the choice made in C++ the compiler
     // materialises the "+v" operands in one arm BEFORE the wait, i.e. copies registers that are still in flight
     // (caught by tests/test_isa_async.py)
-    // k = 2: KEEP operations stay in flight (the pair-step that issued a chunk's item-vector DMAs), k = 1: KEEP_LO (a pair-step that
-    // issued one lane-state row behind its tile loads), k = 0: none
-    const uint32_t k = __builtin_amdgcn_readfirstlane(keep_dma ? 2u : (keep_lo ? 1u : 0u));
+    const uint32_t k = __builtin_amdgcn_readfirstlane(keep_dma ? 1u : 0u);
     asm volatile(
         "s_cmp_eq_u32 %2, 0\n\t"
         "s_cbranch_scc1 .Lsc_wait0_%=\n\t"
-        "s_cmp_eq_u32 %2, 1\n\t"
-        "s_cbranch_scc1 .Lsc_wait1_%=\n\t"
-        "s_waitcnt vmcnt(%3)\n\t"
-        "s_branch .Lsc_waitd_%=\n"
-        ".Lsc_wait1_%=:\n\t"
-        "s_waitcnt vmcnt(%4)\n\t"
+        "s_waitcnt vmcnt(6)\n\t"
         "s_branch .Lsc_waitd_%=\n"
         ".Lsc_wait0_%=:\n\t"
         "s_waitcnt vmcnt(0)\n"
         ".Lsc_waitd_%=:"
         : "+v"(x), "+v"(y)
-        : "s"(k), "n"(KEEP), "n"(KEEP_LO)
+        : "s"(k)
         : "memory", "scc");
     a = __builtin_bit_cast(V, x), b = __builtin_bit_cast(V, y);
 }

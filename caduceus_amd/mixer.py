@@ -288,8 +288,7 @@ class BiMambaMixerFn(torch.autograd.Function):
         # launch would otherwise leave CUs idle (Caduceus-Ph at batch 1)
         k = ops.lsplit_factor(E, SB, Lq, 2)
         args = (L.ScanArgs * 2)()
-        outs, states, lstates = [], [], []
-        need_grad = any(ctx.needs_input_grad)
+        outs, states = [], []
         ycat = torch.empty((2 * E, SB, Lq), dtype=act, device=x2d.device)  # [y_f ; y_r]: one out_proj GEMM with K = 2E
         for i, (xc, delta, A, dbc, Df, bfz, *_rest) in enumerate(sets):
             N, R = A.shape[1], dbc.shape[0] - 2 * A.shape[1]
@@ -301,10 +300,6 @@ class BiMambaMixerFn(torch.autograd.Function):
                                  L.ptr(out), L.ptr(state), SB * k, Lq // k, split * k, E, N, dirs[i][0], dirs[i][1],
                                  L.dtype_code(act))
             args[i].delta_is_dt = int(fused_sp[i])
-            # the state entering every 8-position segment, for the backward (bf16 production shapes; ops.lane_state_buffer)
-            lst = ops.lane_state_buffer(lib, E, SB * k, Lq // k, N, act, xc.device) if (need_grad and all(fused_sp)) else None
-            args[i].lane_state = L.ptr(lst)
-            lstates.append(lst)
             outs.append(out)
             states.append(state)
         _keep, seg_P = ops.scan_fwd_launch(lib, args, 2, stream, k, [st[2] for st in sets], dirs, split)
@@ -320,7 +315,6 @@ class BiMambaMixerFn(torch.autograd.Function):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt = sets[i]
             keep += [xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, states[i], ps[7 * i + 5]]
         ctx.wT = wT  # (not saved tensors: plain per-step copies owned by the cache)
-        ctx.lstates = lstates  # (written by the forward scan kernel, read by the backward one; None where not served)
         ctx.save_for_backward(*keep, *seg_P)
         ctx.meta = (SB, Lq, split, [tuple(None if p is None else (p.dtype, p.shape) for p in ps[7 * i:7 * i + 7])
                                     for i in range(2)], W_in.dtype, W_out.dtype, tuple(fused_sp), k)
@@ -381,7 +375,6 @@ class BiMambaMixerFn(torch.autograd.Function):
                                     L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None, L.ptr(fix_list[i]),
                                     L.ptr(fix_cnt[i]), L.ptr(dxz[E:]) if (_SHARED_GATE or i == 0) else L.ptr(dz))
             args[i].delta_is_dt = int(fused_sp[i])
-            args[i].lane_state = L.ptr(ctx.lstates[i])
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
         _keep = ops.scan_bwd_launch(lib, args, 2, stream, k, seg_P, dirs, split)
         L.check(lib.cad_scan_bwd_gate_fix(args, 2, stream), "cad_scan_bwd_gate_fix")  # no-op unless some z == 0 exactly

@@ -282,7 +282,7 @@ def scan_fwd_launch(lib, args, nsets: int, stream, k: int, As, dirs, split: int)
             C.memmove(C.byref(p1[i]), C.byref(args[i]), C.sizeof(L.ScanArgs))
             hT = torch.empty((E, SBk, N), dtype=torch.float32, device=dev)
             sdt = torch.empty((E, SBk), dtype=torch.float32, device=dev)
-            p1[i].map_only, p1[i].out, p1[i].chunk_state, p1[i].z, p1[i].lane_state = 1, None, None, None, None
+            p1[i].map_only, p1[i].out, p1[i].chunk_state, p1[i].z = 1, None, None, None
             p1[i].h0, p1[i].hT, p1[i].sum_dt = None, L.ptr(hT), L.ptr(sdt)
             hTs.append(hT), sdts.append(sdt)
         L.check(lib.cad_scan_fwd_multi(p1, nsets, stream), "cad_scan_fwd_multi (map pass)")
@@ -309,7 +309,7 @@ def scan_bwd_launch(lib, args, nsets: int, stream, k: int, Ps, dirs, split: int)
             C.memmove(C.byref(p1[i]), C.byref(args[i]), C.sizeof(L.ScanBwdArgs))
             g = torch.empty((E, SBk, N), dtype=torch.float32, device=dev)
             p1[i].carry_only, p1[i].dhT, p1[i].dh0 = 1, None, L.ptr(g)
-            p1[i].dz, p1[i].out2, p1[i].gate_fix_list, p1[i].gate_fix_count, p1[i].lane_state = None, None, None, None, None
+            p1[i].dz, p1[i].out2, p1[i].gate_fix_list, p1[i].gate_fix_count = None, None, None, None
             gs.append(g)
         L.check(lib.cad_scan_bwd_multi(p1, nsets, stream), "cad_scan_bwd_multi (carry pass)")
         for i in range(nsets):
@@ -318,19 +318,6 @@ def scan_bwd_launch(lib, args, nsets: int, stream, k: int, Ps, dirs, split: int)
             keep.append(dhT)
     L.check(lib.cad_scan_bwd_multi(args, nsets, stream), "cad_scan_bwd_multi")
     return keep
-
-
-def lane_state_buffer(lib, E: int, SB: int, Lq: int, N: int, dtype: torch.dtype, device):
-    """cad_scan_args.lane_state / cad_scan_bwd_args.lane_state: the state entering every 8-position segment, written by the bf16 forward
-    for its backward (which then skips the recompute's serial pass + wave scan).  None for the shapes the production kernels do not
-    serve (cad_scan_lane_state_bytes() == 0) and when switched off (CADUCEUS_AMD_LANE_STATES=0: A/B)."""
-    if not LANE_STATES or dtype != torch.bfloat16:
-        return None
-    n = int(lib.cad_scan_lane_state_bytes(int(E), int(SB), int(Lq), int(N), L.dtype_code(dtype)))
-    return torch.empty((n // 4,), dtype=torch.int32, device=device) if n > 0 else None
-
-
-LANE_STATES = os.environ.get("CADUCEUS_AMD_LANE_STATES", "1") != "0"
 
 
 def gate_fix_buffers(lib, u, N):
@@ -352,7 +339,7 @@ class _ScanMulti(torch.autograd.Function):
         z = None if z is None else z.contiguous()
         sets, args = [], (L.ScanArgs * nsets)()
         need_grad = any(ctx.needs_input_grad)
-        outs, lstates = [], []
+        outs = []
         for i in range(nsets):
             u, delta, A, Bm, Cm, D, bias = tensors[7 * i:7 * i + 7]
             u, delta, Bm, Cm = u.contiguous(), delta.contiguous(), Bm.contiguous(), Cm.contiguous()
@@ -366,20 +353,16 @@ class _ScanMulti(torch.autograd.Function):
             out = torch.empty_like(u)
             state = (torch.empty((lib.cad_scan_state_floats(E, SB * k, Lq // k, N),), dtype=torch.float32, device=u.device)
                      if need_grad else None)
-            lstate = lane_state_buffer(lib, E, SB * k, Lq // k, N, u.dtype, u.device) if (need_grad and delta_is_dt) else None
-            stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, out, state, lstate)
+            stream = L.stream_and_check(u, delta, Af, Bm, Cm, Df, z, bf, out, state)
             rl, rh = dirs[i]
             args[i] = L.ScanArgs(L.ptr(u), L.ptr(delta), L.ptr(Af), L.ptr(Bm), L.ptr(Cm), L.ptr(Df), L.ptr(z), L.ptr(bf),
                                  L.ptr(out), L.ptr(state), SB * k, Lq // k, split * k, E, N, rl, rh, L.dtype_code(u.dtype))
             args[i].delta_is_dt = int(bool(delta_is_dt))
-            args[i].lane_state = L.ptr(lstate)
-            lstates.append(lstate)
             sets.append((u, delta, Af, Bm, Cm, Df, bf, state, out))
             outs.append(out)
         _keep, Ps = scan_fwd_launch(lib, args, nsets, stream, k, [s_[2] for s_ in sets], dirs, split)
         flat = [t for s_ in sets for t in s_]
         ctx.save_for_backward(z, *flat, *Ps)
-        ctx.lstates = lstates  # (plain buffers written by the forward kernel, read by the backward kernel; None where not served)
         ctx.meta = (split, dirs, nsets, [(t[2].dtype, t[5].dtype, t[6].dtype) for t in
                                          [tensors[7 * i:7 * i + 7] for i in range(nsets)]], bool(delta_is_dt), k)
         return tuple(outs)
@@ -411,7 +394,6 @@ class _ScanMulti(torch.autograd.Function):
                                     split * k, E, N, rl, rh, L.dtype_code(u.dtype), npart, None, None, None, L.ptr(fix_list),
                                     L.ptr(fix_cnt), L.ptr(dz))
             args[i].delta_is_dt = int(delta_is_dt)
-            args[i].lane_state = L.ptr(ctx.lstates[i])
             keep.append((dout, dBC, fix_list, fix_cnt))
             res.append([du, ddelta, dA, dBC, dD, dbias, dz])
         keep.append(scan_bwd_launch(lib, args, nsets, stream, k, Ps, dirs, split))

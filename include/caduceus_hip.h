@@ -208,12 +208,6 @@ typedef struct {
     int map_only;      /* 1: only the row's affine state map is wanted -- hT (from h0, default 0) and sum_dt are written, `out`
                         * and chunk_state are not touched (may be NULL), C / D / z are not read.  Pass 1 of an L-split scan:
                         * the segments of a row are presented as rows (E, SB * k, L / k) of the same buffers. */
-    void* lane_state;  /* optional (NULL = absent), written: the running state ENTERING every 8-position segment of a row, both states
-                        * of a pair rounded to bf16 in one dword -- (E, SB, ceil(N / 2), L / 8) uint32, cad_scan_lane_state_bytes()
-                        * bytes.  The bf16 backward then starts every lane from its own state and skips the recompute of the running
-                        * states (one serial pass + one wave scan per state pair, ~13 % of its instruction stream) for 1.07 GB of
-                        * stores per BiMamba layer at configs[2].  Served by the bf16 / d_state 16 / L % 16 == 0 production kernels
-                        * only: cad_scan_lane_state_bytes() returns 0 for every other shape and the caller passes NULL. */
 } cad_scan_args;
 int cad_scan_fwd(const cad_scan_args* a, void* stream);
 /* Same, for nsets (1 or 2) independent parameter sets of identical shape in ONE launch -- the mamba_fwd and mamba_rev
@@ -221,8 +215,6 @@ int cad_scan_fwd(const cad_scan_args* a, void* stream);
 int cad_scan_fwd_multi(const cad_scan_args* sets, int nsets, void* stream);
 int64_t cad_scan_chunk_len(void);
 int64_t cad_scan_state_floats(int E, int64_t SB, int64_t L, int N);
-/* Bytes of cad_scan_args.lane_state for this shape, or 0 when the kernels that write / read it do not serve the shape. */
-int64_t cad_scan_lane_state_bytes(int E, int64_t SB, int64_t L, int N, int dtype);
 /* Backward.  du, ddelta, dz are WRITTEN (dtype).  dA (E,N), dD (E), ddelta_bias (E) are ACCUMULATED with a few fp32
  * atomics per channel (caller zeroes).  dB, dC: n_partials = cad_scan_bwd_partials(E) slots of (N,SB,L) each, in the
  * activation dtype (fp32 mode: fp32 slots; bf16 mode: bf16 slots, each holding an fp32-accumulated 8-channel sum);
@@ -276,7 +268,6 @@ typedef struct {
                         * (exp, C * dy, one chain per item and state); no other output is written, B / chunk_state / out are
                         * not read (du, ddelta, dA, dB, dC, dD, ddelta_bias, chunk_state may be NULL).  Pass 1 of an L-split
                         * backward (see map_only). */
-    const void* lane_state;  /* as written by the forward (cad_scan_args.lane_state), or NULL: recompute the running states */
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);

@@ -156,10 +156,6 @@ __device__ __forceinline__ void cad_glds16(const void* gsrc /* per lane */, uint
     std::memcpy(emu::dyn_smem() + lds_base + 16 * emu::lane_id(), gsrc, 16);
 }
 
-__device__ __forceinline__ void cad_glds4(const void* gsrc /* per lane */, uint32_t lds_base /* wave-uniform, SGPR */) {
-    std::memcpy(emu::dyn_smem() + lds_base + 4 * emu::lane_id(), gsrc, 4);
-}
-
 __device__ __forceinline__ void cad_wave_sync() {
     emu::wave_sync();
 }

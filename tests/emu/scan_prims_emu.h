@@ -107,8 +107,8 @@ template <typename V>
 __device__ __forceinline__ void sc_async_wait(V& a, V& b) {
 }
 
-template <int KEEP, int KEEP_LO, typename V>
-__device__ __forceinline__ void sc_async_wait_keep(V& a, V& b, bool keep_dma, bool keep_lo) {
+template <typename V>
+__device__ __forceinline__ void sc_async_wait_keep(V& a, V& b, bool keep_dma) {
 }
 
 template <int KEEP>

@@ -43,9 +43,8 @@ def _walk_to_wait(lines, labels, start, pending, where):
             in_asm = False
         elif not line or line.startswith((";", ".")) and not re.match(r"^\.LBB\d+_\d+:", line) or line.endswith(":"):
             pass
-        elif in_asm and line.startswith(("s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(6)", "s_waitcnt vmcnt(7)", "s_waitcnt vmcnt(1)")):
-            # vmcnt(6) / vmcnt(7) / vmcnt(1): the counted forms of a pair-step in which SC_NDMA = 6 item-vector DMAs (+ one lane-state row
-            # in the backward's lane-state instantiation; that row alone in its other pair-steps) were issued BEHIND the
+        elif in_asm and line.startswith(("s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(6)")):
+            # vmcnt(6): the counted form of the pair-step in which SC_NDMA = 6 LDS-DMA operations were issued BEHIND the
             # tile loads (scan_common.h: sc_async_wait_keep) -- the tile loads are complete, only the DMA stays in flight
             return steps
         elif in_asm and line.startswith("global_load_dword"):
