@@ -116,7 +116,7 @@ def _own_wgrad_chunked(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
 def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
     """a (M, T) channel-major @ b (T, N) token-major -> (M, N) fp32."""
     M, T = a_cm.shape
-    if _OWN_GEMM and b_tm.shape[1] <= 256:  # (one column tile: at d_model 512 the library's K-split is 12 % faster, profiles/r04_gemm_stream.txt)
+    if _OWN_GEMM and (b_tm.shape[1] <= 256 or _OWN_GEMM_D512):  # (one column tile: at d_model 512 the library's K-split was 12 % faster, profiles/r04_gemm_stream.txt)
         own = ops.wgrad_cm_tm(a_cm, b_tm)
         if own is not None:
             return own
@@ -143,6 +143,11 @@ _OWN_OUT_PROJ = os.environ.get("CADUCEUS_AMD_OWN_OUT_PROJ", "1") != "0"
 # d(x2d), dW_in and dW_out -- the products whose two operands both stream -- on the own tiled MFMA kernel (cad_gemm_stream: fp32
 # accumulation over ALL tokens for the weight gradients); CADUCEUS_AMD_OWN_GEMM=0: torch.mm / K-split bmm (hipBLASLt)
 _OWN_GEMM = os.environ.get("CADUCEUS_AMD_OWN_GEMM", "1") != "0"
+# ... also at d_model 512 (configs[4]: two 256-column tiles, the strided operand is walked twice).  The library products are 0.5 ms per
+# layer faster there (31.75 vs 32.28 ms per layer, 535.2 vs 538.2 ms per step: profiles/r05_gemm_stream_d512.txt), i.e. 0.6 % of a step
+# is the price of a configs[4] step without a library GEMM and with fp32-accumulated weight gradients; CADUCEUS_AMD_OWN_GEMM_D512=0
+# takes torch.mm / the K-split bmm for these three products at d_model > 256
+_OWN_GEMM_D512 = os.environ.get("CADUCEUS_AMD_OWN_GEMM_D512", "1") != "0"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
@@ -196,7 +201,7 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
         owners.append((mf, ps + [mf.A_log, mr.A_log], out))
     torch._foreach_copy_(dst, src)
     # (W_in^T feeds cad_gemm_stream's d(x2d) only: d_model <= 256 with the own tiled GEMM on)
-    need_in_T = _OWN_GEMM and "in" in stacked and stacked["in"].shape[2] <= 256
+    need_in_T = _OWN_GEMM and "in" in stacked and (stacked["in"].shape[2] <= 256 or _OWN_GEMM_D512)
     trans = {kd: stacked[kd].transpose(1, 2).contiguous() for kd in ("out", "x", "dt") + (("in",) if need_in_T else ()) if kd in stacked}
     cursor = {kd: 0 for kd in kinds}
 
@@ -452,7 +457,7 @@ class BiMambaMixerFn(torch.autograd.Function):
         # (d_model 256: one 256-row tile, dxz read once; the configs[4] step with all three products on the own kernel measured 570.7 ms
         # against 555.9 ms with the library: d_model 512 stays there)
         dx2d = None
-        if _OWN_GEMM and Dm <= 256:
+        if _OWN_GEMM and (Dm <= 256 or _OWN_GEMM_D512):
             w_inT = wT["in"] if (wT and wT.get("in") is not None) else w_in.t().contiguous()
             dx2d = ops.proj_xTw_stream(w_inT, dxz.view(2 * E, T))
         if dx2d is None:
