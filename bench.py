@@ -180,9 +180,40 @@ def cpu_baseline_worker(scan_L=131072, reps_model=15, reps_scan=3):
     print(json.dumps(res), flush=True)
 
 
-# instruction price of one (channel, position, state pair) element on one SIMD, ns (DESIGN.md section 3 "Floors": the per-pair-step
-# instruction mix of each kernel priced with profiles/r01_ubench_gfx950.log; 0.5 us per 512-position backward pair-step and wave)
-INSTR_PRICE_NS = {"scan_fwd": 0.477, "scan_bwd": 0.977}
+# Issue price of one wave instruction on one SIMD with two resident waves, ns, by instruction class -- this chip's micro-benchmark
+# (tools/ubench/ubench.hip, profiles/r01_ubench_gfx950.log: SIMD ticks per instruction at waves/SIMD = 2: v_mul / v_mov 2.2, v_fma 2.8,
+# v_pk_* and v_cvt_pk 3.6, VOP2 + DPP 3.5, v_exp / v_log / v_rcp 6.2, at the ~1.85 ticks per ns of that run).  "plain" = non-packed
+# VALU incl. moves, selects and v_readlane (between v_mul and v_fma).
+VALU_PRICE_NS = {"valu": 1.15, "valu_mov": 1.0, "valu_sel": 1.0, "valu_lane": 1.0, "valu_pk": 1.95, "valu_dpp": 1.9, "valu_cvt": 1.98,
+                 "trans": 3.4}
+# static instruction mix of the production scan kernels (tools/make_scan_isa_json.py), quoted like the counter profile: only for the
+# scan sources it was counted on
+SCAN_ISA_FILE = os.path.join("profiles", "r05_scan_isa.json")
+
+
+def valu_roofline(kind: str, pmc: dict, isa: dict, avg_ms: float, n_simds: int):
+    """The ceiling that actually binds the scans: VALU issue.  Executed VALU wave-instructions per launch
+    (rocprofv3 SQ_INSTS_VALU, transcendentals included) priced with the class mix of the kernel's chunk loop (static count) and this
+    chip's issue prices, spread over the SIMDs; next to it how busy the counters say the VALU was."""
+    sq = (pmc or {}).get("sq", {}).get(kind)
+    mix = (isa or {}).get("kernels", {}).get(kind, {}).get("chunk_loop_static")
+    if not sq or not mix:
+        return None
+    cls = {k: v for k, v in mix.items() if k in VALU_PRICE_NS}
+    n_static = sum(cls.values())
+    mean_price = sum(VALU_PRICE_NS[k] * v for k, v in cls.items()) / n_static  # ns per executed VALU wave-instruction, by the static mix
+    insts = sq["SQ_INSTS_VALU"]
+    ceiling_ms = insts * mean_price / n_simds * 1e-6
+    return {"insts_valu_per_launch": insts, "insts_valu_per_wave": insts / max(1.0, sq.get("SQ_WAVES", 0.0)),
+            "static_chunk_loop_mix": mix, "positions_per_chunk": isa["kernels"][kind]["positions_per_chunk"],
+            "vgprs": isa["kernels"][kind]["vgprs"], "scratch_bytes": isa["kernels"][kind]["scratch_bytes"],
+            "price_ns_per_wave_instruction": VALU_PRICE_NS, "mean_price_ns": mean_price, "simds": n_simds,
+            "issue_ceiling_ms": ceiling_ms, "kernel_over_issue_ceiling": avg_ms / ceiling_ms,
+            # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: share of a resident wave's lifetime in which one of ITS VALU instructions executes
+            # (two waves per SIMD: twice this value is the SIMD's VALU-busy share); SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: parked at s_waitcnt
+            "valu_active_share_of_wave_cycles": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] if sq.get("SQ_WAVE_CYCLES") else None,
+            "waitcnt_share_of_wave_cycles": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"] if sq.get("SQ_WAVE_CYCLES") else None,
+            "lds_bank_conflict_share": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") else None}
 
 
 # counter profile of the two scan kernels at the headline launch shape (tools/prof_scan.sh + tools/make_scan_pmc_json.py), stamped with
@@ -428,6 +459,7 @@ def main():
         # rocprofv3 --pmc at exactly this launch shape); null for any other shape
         # ... and only when the profile was taken on THIS build of the kernels (cad_version() carries a hash of the sources)
         traffic, traffic_note = None, "no counter profile for this launch shape"
+        pmc_ok = None  # the counter profile, when it belongs to this build AND this launch shape
         try:
             pmc = json.load(open(os.path.join(ROOT, SCAN_PMC_FILE)))
             sh = pmc["shape"]
@@ -435,6 +467,7 @@ def main():
                     sh["rows"] == (2 if args.model == "ps" else 1) * args.batch:
                 why = pmc_quotable(pmc, _lib.version())
                 if why:
+                    pmc_ok = pmc
                     traffic = pmc[dom]["fetch_bytes"] + pmc[dom]["write_bytes"]
                     traffic_note = ("HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, " +
                                     SCAN_PMC_FILE + " taken on " + why)
@@ -444,17 +477,30 @@ def main():
         except (OSError, KeyError, ValueError):
             traffic = None
         if dom:
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": kinds[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
+            isa = None
+            try:
+                from caduceus_amd import _build
+                isa = json.load(open(os.path.join(ROOT, SCAN_ISA_FILE)))
+                if isa.get("scan_src") != _build.scan_source_hash() or not _lib.version().endswith(_build.source_hash()):
+                    isa = None  # counted on other scan sources (or this library is not the build of this tree)
+            except (OSError, ValueError):
+                isa = None
+            n_simds = 4 * (torch.cuda.get_device_properties(dev).multi_processor_count if not emu else 256)
+            valu = {k: valu_roofline(k, pmc_ok, isa, kinds[k]["avg_ms"], n_simds) for k in kinds}
+            # `achieved` / `peak` / `frac` stay what the contract asks for -- algorithmic bytes per launch over the launch time against the
+            # HBM peak -- but the resource that BINDS the scans is VALU issue (two waves per SIMD; `valu`, `arithmetic_floor`), not HBM
+            roofline = {"bound": "valu" if any(valu.values()) else "hbm",
+                        "bound_note": "frac is the HBM fraction the contract asks for; the scans are bound by VALU issue (roofline.valu: executed "
+                                      "VALU wave-instructions priced with this chip's issue rates; roofline.arithmetic_floor: the same arithmetic "
+                                      "timed without memory traffic), as measured in rounds 4 and 5 (DESIGN.md section 3)",
+                        "kernel": dom, "achieved": kinds[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": kinds[dom]["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_note": traffic_note,
+                        "traffic_note": traffic_note, "valu": valu,
                         "avg_launch_ms": kinds[dom]["avg_ms"], "launches": kinds[dom]["launches"],
                         "launches_per_layer_op": kinds[dom]["launches_per_op"],
                         "algorithmic_bytes_per_launch": kinds[dom]["algorithmic_bytes_per_launch"],
-                        # second ceiling: the kernels' instruction mix priced with this chip's micro-benchmark
-                        # (DESIGN.md section 3 "Floors"): ns per (channel, position, state PAIR) and SIMD, 1024 SIMDs
                         "all": {k: {"avg_ms": v["avg_ms"], "achieved_GBps": v["achieved_GBps"],
                                     "hbm_bound_ms": alg[k] / (HBM_PEAK_GBS * 1e9) * 1e3,
-                                    "instruction_price_ms": E * inv_tokens * ((N + 1) // 2) * INSTR_PRICE_NS[k] / 1024 * 1e-6,
                                     "share_of_step": v["total_ms"] / (elapsed * 1e3)} for k, v in kinds.items()},
                         "other_kernels_ms_per_step": {k: prof_all[k][0] for k in prof_all if k not in kinds and prof_all[k][1]},
                         "other_kernels_note": "one extra untimed step with every kernel family timed"}

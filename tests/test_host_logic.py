@@ -222,3 +222,33 @@ def test_tool_scripts_reference_existing_scripts():
             if not os.path.exists(os.path.join(root, "tools", ref)):
                 missing.append((os.path.basename(f), ref))
     assert not missing, missing
+
+
+def test_bench_valu_roofline_object():
+    """bench.valu_roofline: the scans' binding ceiling in the bench line -- executed VALU wave-instructions per launch
+    (counter profile) priced with the class mix of the chunk loop (static count) and the chip's issue prices, over the SIMDs."""
+    import importlib.util
+    import os
+    from caduceus_amd import _build
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pmc = {"sq": {"scan_bwd": {"SQ_INSTS_VALU": 1.2e9, "SQ_WAVES": 2048.0, "SQ_WAVE_CYCLES": 4.0e9, "SQ_ACTIVE_INST_VALU": 1.5e9,
+                               "SQ_WAIT_INST_ANY": 8.0e8, "SQ_LDS_BANK_CONFLICT": 1.0e8, "SQ_LDS_IDX_ACTIVE": 5.0e8}}}
+    isa = {"kernels": {"scan_bwd": {"chunk_loop_static": {"valu": 1000, "valu_pk": 800, "valu_dpp": 400, "trans": 200, "salu": 900, "lds": 150},
+                                    "positions_per_chunk": 512, "vgprs": 249, "scratch_bytes": 0}}}
+    v = bench.valu_roofline("scan_bwd", pmc, isa, 3.4, 1024)
+    mean = (1000 * 1.15 + 800 * 1.95 + 400 * 1.9 + 200 * 3.4) / 2400  # SALU / LDS instructions are not VALU issue slots
+    assert abs(v["mean_price_ns"] - mean) < 1e-9
+    assert abs(v["issue_ceiling_ms"] - 1.2e9 * mean / 1024 * 1e-6) < 1e-9 and abs(v["kernel_over_issue_ceiling"] - 3.4 / v["issue_ceiling_ms"]) < 1e-9
+    assert abs(v["valu_active_share_of_wave_cycles"] - 0.375) < 1e-12 and v["insts_valu_per_wave"] == 1.2e9 / 2048
+    assert bench.valu_roofline("scan_fwd", pmc, isa, 1.0, 1024) is None and bench.valu_roofline("scan_bwd", None, isa, 1.0, 1024) is None
+    # the committed static mix belongs to the scan sources in the tree (tools/make_scan_isa_json.py regenerates it)
+    path = os.path.join(ROOT, bench.SCAN_ISA_FILE)
+    if os.path.exists(path):
+        committed = json.load(open(path))
+        assert committed["scan_src"] == _build.scan_source_hash(), bench.SCAN_ISA_FILE + " was counted on other scan sources: re-run the tool"
+        for kind in ("scan_fwd", "scan_bwd"):
+            k = committed["kernels"][kind]
+            assert k["scratch_bytes"] == 0 and k["vgprs"] <= 256 and k["valu_total"] > 1000

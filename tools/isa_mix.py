@@ -56,6 +56,25 @@ def kernel_body(path, sub):
     raise SystemExit(f"no kernel matching {sub}")
 
 
+def loop_mix(path, sub):
+    """{class: count} over the basic blocks of the kernel's (single, outermost) loop -- the 512 / 1024-position chunk loop of a scan kernel --
+    counted statically over ALL paths (both directions' store variants, gate / no gate, tail variants), plus the kernel name."""
+    name, body = kernel_body(path, sub)
+    tot, inloop = Counter(), False
+    for l in body[1:]:
+        t = l.strip()
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            inloop = "Loop Header" in t or "in Loop" in t
+            continue
+        if not inloop or not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        c = classify(t.split()[0])
+        if c.startswith("valu") and ("row_sh" in t or "row_bcast" in t or "quad_perm" in t or "row_half_mirror" in t or "wave_sh" in t):
+            c = "valu_dpp"
+        tot[c] += 1
+    return name, dict(tot)
+
+
 def main():
     path, sub = sys.argv[1], sys.argv[2]
     name, body = kernel_body(path, sub)
