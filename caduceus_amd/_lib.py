@@ -63,7 +63,7 @@ class ProjTmArgs(C.Structure):
 
 class GemmStreamArgs(C.Structure):
     _fields_ = [("A", _p), ("B", _p), ("out", _p), ("R", _i64), ("C", _i64), ("K", _i64), ("lda", _i64), ("ldb", _i64), ("ldo", _i64),
-                ("nslices", _i), ("mode", _i)]
+                ("nslices", _i), ("mode", _i), ("col_fastest", _i)]
 
 
 class Conv1dBwdArgs(C.Structure):

@@ -840,12 +840,20 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_
     if (i0 >= nitems) return;
     const int64_t nmine = (nitems - i0 + istep - 1) / istep;
     const int64_t total = nmine * nk;
-    // work item -> (slice, column tile, row tile), row tiles fastest: neighbouring workgroups share the B rows of a slice
+    // work item -> (slice, column tile, row tile).  Row tiles fastest: neighbouring workgroups share the B rows of a slice; col_fastest:
+    // neighbouring workgroups share an A tile (A = the streamed activations of in_proj / d(y), all of B cache-resident)
     auto decode = [&](int64_t item, int64_t& rt, int64_t& ct, int64_t& sl) {
-        rt = item % nrt;
-        const int64_t q = item / nrt;
-        ct = q % nct;
-        sl = q / nct;
+        if (a.col_fastest) {
+            ct = item % nct;
+            const int64_t q = item / nct;
+            rt = q % nrt;
+            sl = q / nrt;
+        } else {
+            rt = item % nrt;
+            const int64_t q = item / nrt;
+            ct = q % nct;
+            sl = q / nct;
+        }
     };
     // issue cursor
     int ich = 0, islot = 0;

@@ -148,6 +148,9 @@ _OWN_GEMM = os.environ.get("CADUCEUS_AMD_OWN_GEMM", "1") != "0"
 # is the price of a configs[4] step without a library GEMM and with fp32-accumulated weight gradients; CADUCEUS_AMD_OWN_GEMM_D512=0
 # takes torch.mm / the K-split bmm for these three products at d_model > 256
 _OWN_GEMM_D512 = os.environ.get("CADUCEUS_AMD_OWN_GEMM_D512", "1") != "0"
+# in_proj and d(y) at d_model 512 on the same tiled kernel (cad_gemm_stream, column tiles fastest) instead of the W-stationary cad_proj_wxT,
+# which streams the token operand once per 128-row block of W (16 times at M = 2048); CADUCEUS_AMD_STREAM_PROJ_D512=0: cad_proj_wxT
+_STREAM_PROJ_D512 = os.environ.get("CADUCEUS_AMD_STREAM_PROJ_D512", "1") != "0"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
@@ -255,6 +258,10 @@ class BiMambaMixerFn(torch.autograd.Function):
             # e4m3 activations + per-token scales: written by the add + norm kernel that produced x2d (fp8_act), else quantised here
             xq, sx = (fp8_act[0].view(T, Dm), fp8_act[1]) if fp8_act is not None else ops.quant_rows_fp8(x2d)
             xz = ops.proj_wxT_fp8(wq, sw, xq, sx).view(2 * E, SB, Lq)
+        elif _STREAM_PROJ_D512 and Dm > 256 and act == torch.bfloat16 and cache is not None and (cache.get("wT") or {}).get("in") is not None \
+                and (xz_s := ops.gemm_out_t(x2d, cache["wT"]["in"])) is not None:
+            # d_model 512: both operands streamed through the tiled kernel (A = tokens, B = W_in^T from the step cache), channel-major result
+            xz = xz_s.view(2 * E, SB, Lq)
         elif ops.proj_supported(x2d, Dm):  # bf16: our W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
             xz = ops.proj_wxT(w_in, x2d).view(2 * E, SB, Lq)
         else:
@@ -339,7 +346,13 @@ class BiMambaMixerFn(torch.autograd.Function):
         dout2d = dout2d.contiguous()
         # tied out_proj: the gradient w.r.t. y_f and y_r is the same tensor, produced channel-major
         wT = ctx.wT
-        if ops.proj_supported(dout2d, Dm):
+        dy = None
+        if _STREAM_PROJ_D512 and Dm > 256 and act == torch.bfloat16:
+            dy = ops.gemm_out_t(dout2d, w_out)  # (T, D) @ W_out (D, E) -> (E, T): the weight as it lies is the row-major B operand
+            dy = None if dy is None else dy.view(E, SB, Lq)
+        if dy is not None:
+            pass
+        elif ops.proj_supported(dout2d, Dm):
             dy = ops.proj_wxT(wT["out"] if wT else w_out.t().contiguous(), dout2d).view(E, SB, Lq)
         else:
             dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)

@@ -694,7 +694,15 @@ def wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> Optional[torch.Tensor
     return part[0] if n == 1 else part.sum(0)
 
 
-def proj_xTw_stream(Wt: torch.Tensor, X: torch.Tensor) -> Optional[torch.Tensor]:
+def gemm_out_t(A: torch.Tensor, B: torch.Tensor, col_fastest: bool = True) -> Optional[torch.Tensor]:
+    """out (C, R) bf16 = (A (R, K) @ B (K, C))^T, both operands row-major bf16 and streamed, fp32 accumulation (cad_gemm_stream,
+    CAD_GEMM_OUT_T_BF16).  With A = token-major activations (T, d_model) and B = W^T (d_model, M) this is a projection with channel-major
+    output (M, T): the in_proj and d(y) of the mixer at d_model 512 (configs[4]), where it replaces the W-stationary cad_proj_wxT
+    (which streams X once per 128-row block of W).  col_fastest: neighbouring workgroups share an A tile.  None if the shape is not served."""
+    return proj_xTw_stream(A, B, col_fastest=col_fastest)
+
+
+def proj_xTw_stream(Wt: torch.Tensor, X: torch.Tensor, col_fastest: bool = False) -> Optional[torch.Tensor]:
     """out (T, M) token-major bf16 = X (K, T)^T @ Wt (M, K)^T with X channel-major and BOTH operands streamed (cad_gemm_stream,
     CAD_GEMM_OUT_T_BF16): d(x2d) = dxz^T W_in with Wt = W_in^T (D, 2E), K = 2E too deep for resident weight fragments.  None if the
     shape is not served."""
@@ -708,7 +716,8 @@ def proj_xTw_stream(Wt: torch.Tensor, X: torch.Tensor) -> Optional[torch.Tensor]
         return None
     out = torch.empty((T, M), dtype=torch.bfloat16, device=X.device)
     stream = L.stream_and_check(Wt, X, out, contiguous=False)
-    a = L.GemmStreamArgs(L.ptr(Wt), L.ptr(X), L.ptr(out), M, T, K, Wt.stride(0), X.stride(0), out.stride(0), 1, GEMM_OUT_T_BF16)
+    a = L.GemmStreamArgs(L.ptr(Wt), L.ptr(X), L.ptr(out), M, T, K, Wt.stride(0), X.stride(0), out.stride(0), 1, GEMM_OUT_T_BF16,
+                         int(bool(col_fastest)))
     L.check(L.get_lib().cad_gemm_stream(C.byref(a), stream), "cad_gemm_stream")
     return out
 

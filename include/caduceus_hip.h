@@ -366,7 +366,13 @@ int cad_proj_xTw_supported(int M, int K, int64_t T);
  *   tile to partials[s][R][C] (the caller sums the slices in fp32: a weight gradient over all tokens, K = T);
  * mode CAD_GEMM_OUT_T_BF16: out (C x R) bf16 = D^T, rows ldo elements apart (token-major d(x2d): A = W_in^T (D x 2E), B = dxz
  *   (2E x T) channel-major, C = T; nslices must be 1).
- * R, C multiples of 256, K / nslices a multiple of 32 (cad_gemm_stream_supported); 16-byte aligned operands, lda / ldb % 8 == 0. */
+ *   Round 5: with K = d_model 512 the same mode is the in_proj itself and d(y) of configs[4] -- A = the token-major activations
+ *   (T x d_model), B = W_in^T (d_model x 2E) resp. W_out (d_model x E), out = the channel-major (2E | E) x T result -- where the
+ *   W-stationary cad_proj_wxT streams X once per 128-row block of W (sixteen times at M = 2048).
+ * R, C multiples of 256, K / nslices a multiple of 32 (cad_gemm_stream_supported); 16-byte aligned operands, lda / ldb % 8 == 0.
+ * col_fastest: order of the 256 x 256 tiles over the workgroups -- 0: row tiles fastest (neighbouring workgroups share the B rows of a
+ *   slice: the weight gradients, d(x2d)), 1: column tiles fastest (neighbouring workgroups share an A tile: A is the big streamed
+ *   operand and all of B stays cache-resident, the in_proj / d(y) use).  Placement only; the results are the same. */
 #define CAD_GEMM_PARTIALS 0
 #define CAD_GEMM_OUT_T_BF16 1
 typedef struct {
@@ -377,6 +383,7 @@ typedef struct {
     int64_t lda, ldb, ldo;
     int nslices;
     int mode;
+    int col_fastest;
 } cad_gemm_stream_args;
 int cad_gemm_stream(const cad_gemm_stream_args* a, void* stream);
 int cad_gemm_stream_supported(int64_t R, int64_t C, int64_t K, int nslices);

@@ -347,3 +347,25 @@ def test_mixer_layer_bf16_production_scans_against_the_generic_fp32_path(backend
     for k in ref:
         rel = float((fast[k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-20))
         assert rel < 3e-2, (k, rel)
+
+
+@pytest.mark.parametrize("M,K,T", [(512, 512, 512), (256, 64, 768), (1024, 512, 256)])
+def test_gemm_out_t_as_a_projection_with_column_tiles_fastest(backend, M, K, T):
+    """cad_gemm_stream / CAD_GEMM_OUT_T_BF16 with col_fastest = 1 as the d_model 512 in_proj / d(y): out (M, T) channel-major =
+    W (M, K) . X (T, K)^T computed as (X @ W^T)^T with BOTH operands streamed -- against the fp32 product, against the W-stationary
+    cad_proj_wxT on the same operands (same products, fp32 accumulation: within one bf16 rounding), identical to the row-tiles-fastest
+    placement (placement only), and position-independent (the RC-equivariance property of the t-frame)."""
+    name, dev = backend
+    W, X = _bf(M, K, seed=51), _bf(T, K, seed=52)
+    Wt = W.t().contiguous()
+    out = ops.gemm_out_t(X.to(dev), Wt.to(dev))
+    assert out is not None and out.shape == (M, T) and out.dtype == torch.bfloat16
+    ref = W.float() @ X.float().t()
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max()) / 8)
+    assert torch.equal(out.cpu(), ops.proj_xTw_stream(X.to(dev), Wt.to(dev), col_fastest=False).cpu())
+    if ops.proj_supported(X.to(dev), K):
+        wxT = ops.proj_wxT(W.to(dev), X.to(dev))
+        torch.testing.assert_close(out.float().cpu(), wxT.float().cpu(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 8)
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(6))
+    out_p = ops.gemm_out_t(X[perm].contiguous().to(dev), Wt.to(dev))
+    assert torch.equal(out.cpu()[:, perm], out_p.cpu())

@@ -34,6 +34,13 @@ for M in (2048, 1024):
         res["own_ms"] = round(timeit(lambda: ops.proj_wxT(W, X, out=out)), 4)
         res["own_TBps"] = round(by / res["own_ms"] / 1e9, 2)
         res["own_TFLOPs"] = round(2.0 * T * K * M / res["own_ms"] / 1e9, 1)
+    if only != "lib":  # round 5: both operands streamed through the tiled kernel, column tiles fastest (ops.gemm_out_t)
+        Wt = W.t().contiguous()
+        for cf in (True, False):
+            key = "stream_ms" if cf else "stream_rowfast_ms"
+            res[key] = round(timeit(lambda: ops.proj_xTw_stream(X, Wt, col_fastest=cf)), 4)
+        res["stream_TBps"] = round(by / res["stream_ms"] / 1e9, 2)
+        res["stream_TFLOPs"] = round(2.0 * T * K * M / res["stream_ms"] / 1e9, 1)
     if only != "own":
         res["hipblaslt_ms"] = round(timeit(lambda: torch.mm(W, X.t(), out=out)), 4)
         res["hipblaslt_TBps"] = round(by / res["hipblaslt_ms"] / 1e9, 2)
