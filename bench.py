@@ -489,7 +489,8 @@ def main():
             valu = {k: valu_roofline(k, pmc_ok, isa, kinds[k]["avg_ms"], n_simds) for k in kinds}
             # `achieved` / `peak` / `frac` stay what the contract asks for -- algorithmic bytes per launch over the launch time against the
             # HBM peak -- but the resource that BINDS the scans is VALU issue (two waves per SIMD; `valu`, `arithmetic_floor`), not HBM
-            roofline = {"bound": "valu" if any(valu.values()) else "hbm",
+            roofline = {"bound": "valu",  # (the dominant kernels are the scans at every configuration; `valu` carries the counters where a
+                                          #  counter profile of this build and launch shape exists, null elsewhere)
                         "bound_note": "frac is the HBM fraction the contract asks for; the scans are bound by VALU issue (roofline.valu: executed "
                                       "VALU wave-instructions priced with this chip's issue rates; roofline.arithmetic_floor: the same arithmetic "
                                       "timed without memory traffic), as measured in rounds 4 and 5 (DESIGN.md section 3)",
