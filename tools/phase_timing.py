@@ -37,18 +37,20 @@ def main():
     r = lambda *sh: torch.randn(*sh, generator=g).to(dev).to(torch.bfloat16)
     u, d, z, B, Cm = r(E, SB, L), r(E, SB, L), r(E, SB, L), r(N, SB, L), r(N, SB, L)
     u2, d2, B2, C2 = r(E, SB, L), r(E, SB, L), r(N, SB, L), r(N, SB, L)
+    # the production path hands the scans dt itself (softplus in the dt_proj epilogue): the lean backward instantiation
+    d, d2 = (torch.nn.functional.softplus(t.float() - 3.0).to(torch.bfloat16) for t in (d, d2))
     A = -(torch.arange(1, N + 1).float().repeat(E, 1)).to(dev)
     D, bias = torch.ones(E, device=dev), (torch.randn(E, generator=g) - 4).to(dev)
     sets = [(u, d, A, B, Cm, D, bias), (u2, d2, A, B2, C2, D, bias)]
     gsets = [tuple(x.clone().requires_grad_(True) for x in st) for st in sets]
     zg = z.clone().requires_grad_(True)
-    o1, o2 = ops.selective_scan_multi(gsets, zg, 1, [(0, 1), (1, 0)])
+    o1, o2 = ops.selective_scan_multi(gsets, zg, 1, [(0, 1), (1, 0)], delta_is_dt=True)
     g1, g2 = torch.randn_like(o1), torch.randn_like(o2)
     torch.cuda.synchronize()
     read(raw, "cad_debug_timing_fwd", True)
     reps = 3
     for _ in range(reps):
-        ops.selective_scan_multi(sets, z, 1, [(0, 1), (1, 0)])
+        ops.selective_scan_multi(sets, z, 1, [(0, 1), (1, 0)], delta_is_dt=True)
     torch.cuda.synchronize()
     fwd = read(raw, "cad_debug_timing_fwd", True)
     read(raw, "cad_debug_timing_bwd", True)
