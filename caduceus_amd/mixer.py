@@ -258,14 +258,18 @@ class BiMambaMixerFn(torch.autograd.Function):
             # e4m3 activations + per-token scales: written by the add + norm kernel that produced x2d (fp8_act), else quantised here
             xq, sx = (fp8_act[0].view(T, Dm), fp8_act[1]) if fp8_act is not None else ops.quant_rows_fp8(x2d)
             xz = ops.proj_wxT_fp8(wq, sw, xq, sx).view(2 * E, SB, Lq)
-        elif _STREAM_PROJ_D512 and Dm > 256 and act == torch.bfloat16 and cache is not None and (cache.get("wT") or {}).get("in") is not None \
-                and (xz_s := ops.gemm_out_t(x2d, cache["wT"]["in"])) is not None:
-            # d_model 512: both operands streamed through the tiled kernel (A = tokens, B = W_in^T from the step cache), channel-major result
-            xz = xz_s.view(2 * E, SB, Lq)
-        elif ops.proj_supported(x2d, Dm):  # bf16: our W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
-            xz = ops.proj_wxT(w_in, x2d).view(2 * E, SB, Lq)
         else:
-            xz = torch.mm(w_in, x2d.t()).view(2 * E, SB, Lq)
+            xz = None
+            w_inT = ((cache or {}).get("wT") or {}).get("in")
+            if _STREAM_PROJ_D512 and Dm > 256 and act == torch.bfloat16 and w_inT is not None:
+                # d_model 512: both operands streamed through the tiled kernel (A = tokens, B = W_in^T from the step cache), channel-major
+                # result (None if the shape is not served)
+                xz = ops.gemm_out_t(x2d, w_inT)
+            if xz is None and ops.proj_supported(x2d, Dm):  # bf16: the W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
+                xz = ops.proj_wxT(w_in, x2d)
+            if xz is None:
+                xz = torch.mm(w_in, x2d.t())
+            xz = xz.view(2 * E, SB, Lq)
         x, z = xz[:E], xz[E:]
         sets, saved = [], []
         dirs = ((0, 1), (1, 0))
@@ -349,13 +353,11 @@ class BiMambaMixerFn(torch.autograd.Function):
         dy = None
         if _STREAM_PROJ_D512 and Dm > 256 and act == torch.bfloat16:
             dy = ops.gemm_out_t(dout2d, w_out)  # (T, D) @ W_out (D, E) -> (E, T): the weight as it lies is the row-major B operand
-            dy = None if dy is None else dy.view(E, SB, Lq)
-        if dy is not None:
-            pass
-        elif ops.proj_supported(dout2d, Dm):
-            dy = ops.proj_wxT(wT["out"] if wT else w_out.t().contiguous(), dout2d).view(E, SB, Lq)
-        else:
-            dy = torch.mm(w_out.t(), dout2d.t()).view(E, SB, Lq)
+        if dy is None and ops.proj_supported(dout2d, Dm):
+            dy = ops.proj_wxT(wT["out"] if wT else w_out.t().contiguous(), dout2d)
+        if dy is None:
+            dy = torch.mm(w_out.t(), dout2d.t())
+        dy = dy.view(E, SB, Lq)
         y_f, y_r = ycat[:E], ycat[E:]
         dW_cat = _wgrad_cm_tm(ycat.view(2 * E, T), dout2d)  # (2E, D): both halves multiply the same tied weight
         dW_out = (dW_cat[:E] + dW_cat[E:]).t()
