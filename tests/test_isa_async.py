@@ -158,3 +158,33 @@ def test_gemm_stream_counted_waits_match_the_issued_operations(tmp_path):
         else:                # CAD_GEMM_PARTIALS: the fp32 tile leaves once, behind the last chunk
             assert waits == {0, 8}, (name, waits)
             assert len(re.findall(r"global_store_dword\b", body)) == 128, name
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_legacy_multiply_is_compiler_visible(tmp_path):
+    """Round 5, found on the device: `v_mul_legacy_f32` written as inline asm read a `v_rcp_f32` result one wait state early (a transcendental
+    -> VALU hazard the compiler pads only for instructions it can see; the host emulator cannot show it) -- dz of the first item of ~10 % of the
+    lanes came out 0.  The instruction must reach the kernel through the LLVM intrinsic: present in the lean backward instantiation, never
+    inside an inline-asm block, and never issued directly behind the transcendental that produces its operand."""
+    out = tmp_path / "scan_bwd.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(ROOT, "caduceus_amd", "csrc", "scan_bwd.hip")], stderr=subprocess.DEVNULL)
+    bodies = _kernel_bodies(open(out).read())
+    lean = [b for n, b in bodies.items() if "scan_bwd_kernelI6bf16_tLb1ELb0ELi8ELb1E" in n]
+    assert len(lean) == 1
+    lines = [l.strip() for l in lean[0].split("\n")]
+    in_asm, n, prev = False, 0, ""
+    for t in lines:
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        elif t.startswith("v_mul_legacy_f32"):
+            n += 1
+            assert not in_asm, "v_mul_legacy_f32 inside an inline-asm block"
+            m = re.match(r"(v_rcp_f32|v_exp_f32|v_log_f32)\w*\s+(v\d+)", prev)
+            if m:  # the instruction right in front is a transcendental: it must not be the producer of one of the operands
+                assert m.group(2) not in re.split(r"[,\s]+", t)[2:], f"`{prev}` directly in front of `{t}`"
+        if t and not t.startswith((";", ".")):
+            prev = t
+    assert n >= 8, n  # one per item of a lane's segment in the gate gradient
