@@ -82,6 +82,10 @@ static_assert(SC_S_BWD == 8, "the backward scan is written for 8 items per lane 
 #ifndef SC_BWD_UNROLL_NP
 #define SC_BWD_UNROLL_NP 8
 #endif
+#ifndef SC_BWD_FLUSH_HALF
+#define SC_BWD_FLUSH_HALF 1   // which waves run the MFMA flush of a pair-step's dB / dC slab: 1 = the staging waves 0-3 (both tensors of their
+                              // lane block), 0 = all eight (one tile pair each), 2 = waves 4-7
+#endif
 #ifndef SC_BWD_LEAN
 #define SC_BWD_LEAN 1   // 0: the round-4 prologue / epilogue / per-pair-step dA wave sum for every launch (A/B switch)
 #endif
@@ -627,8 +631,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             if constexpr (CO) continue;  // no slab, no flush
             if constexpr (PACKED) {
                 if (!(SC_WHATIF & 32)) {
-                // wave w sums tensor (w >> 2), lanes 16 (w & 3) .. + 15 over the 8 channels on the matrix core
-                const int ten = wave >> 2, jb = wave & 3;
+                // one (tensor, 16-lane block) tile pair per call: tensor `ten`, lanes 16 jb .. + 15, summed over the 8 channels on the matrix core
+                auto flush_tile = [&](const int ten, const int jb) {
                 const int g = lane >> 4, jl = lane & 15;
                 const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + (jb * 16 + jl) * 4 + g * (2 * PK_TILE);
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
@@ -670,6 +674,22 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                         }
                     }
                 }
+                };  // flush_tile
+#if SC_BWD_FLUSH_HALF == 0
+                flush_tile(wave >> 2, wave & 3);  // every wave one tile pair (rounds 2-4)
+#else
+                // the STAGING waves 0-3 flush both tensors of their lane block, waves 4-7 go straight on (SC_BWD_FLUSH_HALF = 2: the other
+                // way round).  Waves 4-7 are the ones that reach the pair-step's barrier last (each shares its SIMD with a staging wave that
+                // wins the VALU arbitration by age, then waits for its tile loads): the flush -- LDS reads, four matrix products, a store,
+                // hardly any VALU work -- costs the staging waves waiting time they have and takes ~30 instructions + a latency chain out of
+                // the critical waves' pair-step.  Same-box: 3.391 vs 3.458 ms (-1.9 %); the other half: +1.2 % (profiles/r05_ab_flush_placement.txt).
+                // (NOT unrolled: with both tiles' address arithmetic hoisted out of the chunk loop the kernel spills -- 256 VGPRs + 156 bytes
+                // of scratch, +24 % -- while this form needs 223.)
+                if ((wave < SC_W / 2) == (SC_BWD_FLUSH_HALF == 1)) {  // wave-uniform
+#pragma unroll 1
+                    for (int ften = 0; ften < 2; ++ften) flush_tile(ften, wave & 3);
+                }
+#endif
                 }  // SC_WHATIF & 32
             } else {
                 constexpr int QT = 64 * SC_W / 4;     // threads per (tensor, state)
