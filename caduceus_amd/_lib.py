@@ -118,7 +118,7 @@ class LmHeadArgs(C.Structure):
 class LmHeadBwdArgs(C.Structure):
     _fields_ = [("hidden", _p), ("weight", _p), ("comp", _p), ("labels", _p), ("logits", _p), ("dlogits", _p),
                 ("loss_scale", _p), ("dhidden", _p), ("dw_partials", _p), ("rows", _i64), ("D", _i), ("V", _i),
-                ("n_strands", _i), ("ignore_index", _i64), ("dtype", _i)]
+                ("n_strands", _i), ("ignore_index", _i64), ("dtype", _i), ("ld", _i64)]
 
 
 # every exported symbol of include/caduceus_hip.h: name -> (restype, argtypes)

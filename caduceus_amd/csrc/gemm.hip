@@ -463,12 +463,19 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void proj_wx_thin_kernel(cad_proj
         slot = (slot + 1) & (C::RING - 1);
         if (++ch == NCH) {
             const int64_t t = blk * C::NT + wave * 16 + g * 4;  // this lane's four consecutive tokens
+            const bf16_t* acc = (const bf16_t*)a.acc;  // wave-uniform: the other K half of a product too deep for one W copy in LDS
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int m = mb * 16 + jl;
+                f32x4 v = d[mb];
+                if (acc && m < M && t + 4 <= T) {  // out = bf16(acc + the fp32 sums): the addend is widened, the sum rounded once
+                    const u32x2 o = *(const u32x2*)(acc + (int64_t)m * a.ldacc + t);
+                    v[0] += cad_bits2f(o[0] << 16), v[1] += cad_bits2f(o[0] & 0xFFFF0000u);
+                    v[2] += cad_bits2f(o[1] << 16), v[3] += cad_bits2f(o[1] & 0xFFFF0000u);
+                }
                 u32x2 pk;
-                pk[0] = cad_pack_bf16x2_safe(d[mb][0], d[mb][1]);
-                pk[1] = cad_pack_bf16x2_safe(d[mb][2], d[mb][3]);
+                pk[0] = cad_pack_bf16x2_safe(v[0], v[1]);
+                pk[1] = cad_pack_bf16x2_safe(v[2], v[3]);
                 if (m < M && t + 4 <= T) *(u32x2*)(out + (int64_t)m * a.ldo + t) = pk;
             }
             ch = 0;
@@ -1008,7 +1015,8 @@ static int launch_wx(const cad_proj_args* a, void* stream) {
 }
 
 extern "C" int cad_proj_wx_supported(int K, int64_t T) { return K >= 8 && K <= 64 && (K % 8) == 0 && T >= 8 && (T % 8) == 0; }
-// thin M / deep K variant (x_proj, d(dt_lr)): M <= 64 output rows, K a multiple of 64 up to 1024, no addend
+// thin M / deep K variant (x_proj, d(dt_lr)): M <= 64 output rows, K a multiple of 64 up to 1024; the addend (may alias out) carries the
+// other K half of a product whose W does not fit LDS in one piece (x_proj at d_inner 1024: 64 rows x 1024)
 extern "C" int cad_proj_wx_thin_supported(int M, int K, int64_t T) {
     return M >= 1 && M <= 64 && K > 64 && K <= 1024 && (K % 64) == 0 && T >= 8 && (T % 8) == 0 &&
            GtCfg::lds(M, K) <= 160 * 1024;
@@ -1028,10 +1036,11 @@ static int launch_wx_thin(const cad_proj_args* a, void* stream) {
 
 extern "C" int cad_proj_wx(const cad_proj_args* a, void* stream) {
     CAD_CHECK_ARG(a && a->W && a->X && a->out && a->T > 0 && a->M > 0 && a->K > 0);
-    if (a->acc == nullptr && a->act == 0 && cad_proj_wx_thin_supported(a->M, a->K, a->T)) {
+    if (a->act == 0 && cad_proj_wx_thin_supported(a->M, a->K, a->T)) {
         CAD_CHECK_ARG(a->ldw >= a->K && a->ldx >= a->T && a->ldo >= a->T);
         CAD_CHECK_ARG((a->ldw % 8) == 0 && (a->ldx % 8) == 0 && (a->ldo % 4) == 0);
         CAD_CHECK_ARG((((uintptr_t)a->W | (uintptr_t)a->X) % 16) == 0 && ((uintptr_t)a->out % 8) == 0);
+        CAD_CHECK_ARG(a->acc == nullptr || (a->ldacc >= a->T && (a->ldacc % 4) == 0 && ((uintptr_t)a->acc % 8) == 0));
         CadProfScope prof(8, stream);
         switch ((a->M + 15) / 16) {
             case 1: return launch_wx_thin<1>(a, stream);

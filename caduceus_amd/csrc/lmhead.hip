@@ -255,13 +255,14 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_bwd_mfma_kernel(cad_lm_
     const int64_t rows = a.rows;
     const int64_t ntiles = (rows + 15) / 16;
     float* gs = gs_all[wave];
+    const int64_t LD = a.ld ? a.ld : D;  // row stride of hidden / dhidden / weight / dW-slot rows: a channel block of a wider head
     const float coef = a.loss_scale ? a.loss_scale[0] : 0.f;
     // A fragments of d hidden^T: W[v = 4m + g][channel jl * NCB + cb]  (rows v >= V are zero)
     float wreg[4][NCB];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) wreg[m][cb] = (4 * m + g) < V ? a.weight[(int64_t)(4 * m + g) * D + jl * NCB + cb] : 0.f;
+        for (int cb = 0; cb < NCB; ++cb) wreg[m][cb] = (4 * m + g) < V ? a.weight[(int64_t)(4 * m + g) * LD + jl * NCB + cb] : 0.f;
     int cperm[4];  // strand 1: column comp[4m + g] of the G tile feeds k = 4m + g
 #pragma unroll
     for (int m = 0; m < 4; ++m) cperm[m] = (a.n_strands == 2 && 4 * m + g < V) ? (int)a.comp[4 * m + g] : 4 * m + g;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_bwd_mfma_kernel(cad_lm_
             if (tok) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    T* dst = dh + ((int64_t)s * rows + trow) * D + (4 * g + r) * NCB;
+                    T* dst = dh + ((int64_t)s * rows + trow) * LD + (4 * g + r) * NCB;
 #pragma unroll
                     for (int q = 0; q < NCB; q += 4) {
                         const float v4[4] = {z[q][r], z[q + 1][r], z[q + 2][r], z[q + 3][r]};
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_bwd_mfma_kernel(cad_lm_
                 int64_t hrow = tile * 16 + 4 * m + g;
                 const bool hok = hrow < rows;
                 hrow = hok ? hrow : rows - 1;
-                const T* src = hid + ((int64_t)s * rows + hrow) * D + jl * NCB;
+                const T* src = hid + ((int64_t)s * rows + hrow) * LD + jl * NCB;
                 float hv[NCB];
 #pragma unroll
                 for (int q = 0; q < NV; ++q) {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_bwd_mfma_kernel(cad_lm_
                 const f32x4 o = *(const f32x4*)(&fold[w][cb][lane * 4]);
                 dw[cb][0] += o[0], dw[cb][1] += o[1], dw[cb][2] += o[2], dw[cb][3] += o[3];
             }
-        float* slot = a.dw_partials + (int64_t)blockIdx.x * V * D;
+        float* slot = a.dw_partials + (int64_t)blockIdx.x * V * LD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int v = 4 * g + r;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(64 * LM_WAVES) void lm_head_bwd_mfma_kernel(cad_lm_
 #pragma unroll
                 for (int q = 0; q < NCB; q += 4) {
                     const float v4[4] = {dw[q][r], dw[q + 1][r], dw[q + 2][r], dw[q + 3][r]};
-                    cad_cvt_store<float, 4>(slot + (int64_t)v * D + jl * NCB + q, v4);
+                    cad_cvt_store<float, 4>(slot + (int64_t)v * LD + jl * NCB + q, v4);
                 }
             }
         }
@@ -480,6 +481,7 @@ extern "C" int cad_lm_head_bwd(const cad_lm_head_bwd_args* a, void* stream) {
     CAD_CHECK_ARG(!a->labels || (a->logits && a->loss_scale));
     CAD_CHECK_ARG(a->labels || a->dlogits);
     if (!cad_lm_head_bwd_supported(a->D, a->V) || (a->dtype != CAD_F32 && a->dtype != CAD_BF16)) return CAD_ERR_UNSUPPORTED;
+    CAD_CHECK_ARG(a->ld == 0 || (a->ld >= a->D && (a->ld % 8) == 0));
     CAD_CHECK_ARG((((uintptr_t)a->hidden | (uintptr_t)a->dhidden | (uintptr_t)a->dw_partials) % 16) == 0);
     CadProfScope prof(7, stream);
     dim3 grid((unsigned)lm_head_bwd_blocks(a->rows)), block(64 * LM_WAVES);

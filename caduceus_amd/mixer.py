@@ -151,6 +151,9 @@ _OWN_GEMM_D512 = os.environ.get("CADUCEUS_AMD_OWN_GEMM_D512", "1") != "0"
 # in_proj and d(y) at d_model 512 on the same tiled kernel (cad_gemm_stream, column tiles fastest) instead of the W-stationary cad_proj_wxT,
 # which streams the token operand once per 128-row block of W (16 times at M = 2048); CADUCEUS_AMD_STREAM_PROJ_D512=0: cad_proj_wxT
 _STREAM_PROJ_D512 = os.environ.get("CADUCEUS_AMD_STREAM_PROJ_D512", "1") != "0"
+# A/B switch: out_proj and x_proj at d_model 512 as plain torch products (hipBLASLt) instead of cad_gemm_stream / the two K halves of
+# cad_proj_wx -- the library is ~1.3 % of the configs[4] step faster on these two (profiles/r05_step_trace_c4.txt); default: own kernels
+_LIB_OUT_X_D512 = os.environ.get("CADUCEUS_AMD_LIB_OUT_X_PROJ_D512", "0") == "1"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
@@ -288,6 +291,12 @@ class BiMambaMixerFn(torch.autograd.Function):
             w_x, w_dt = (cache["w"][2 + 2 * i], cache["w"][3 + 2 * i]) if cache else (W_x.to(act), W_dt.to(act))
             if ops.proj_wx_supported(xc, E, T, M=R + 2 * N):  # thin-M / deep-K MFMA kernel: xc read once, W_x in LDS
                 dbc = ops.proj_wx(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
+            elif not _LIB_OUT_X_D512 and E % 128 == 0 and ops.proj_wx_supported(xc, E // 2, T, M=R + 2 * N):
+                # d_inner 1024 (configs[4]): 64 rows x 1024 of W_x do not fit LDS next to the X ring -- two K halves, the second with the
+                # first as its addend (fp32 sums + the widened addend, rounded once); xc is still read once
+                dbc = ops.proj_wx(w_x[:, :E // 2], xc.view(E, T)[:E // 2])
+                ops.proj_wx(w_x[:, E // 2:], xc.view(E, T)[E // 2:], out=dbc, acc=dbc)
+                dbc = dbc.view(R + 2 * N, SB, Lq)
             else:
                 dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
             if ops.proj_wx_supported(xc, R, T):  # thin-K MFMA kernel (transposing LDS reads), csrc/gemm.hip
@@ -324,7 +333,13 @@ class BiMambaMixerFn(torch.autograd.Function):
             # W_out (y_f + y_r): both panels through one set of resident W_out fragments, token-major output (cad_proj_xTw)
             out2d = ops.proj_xTw(w_out, y_f.view(E, T), y_r.view(E, T))
         else:
-            out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
+            # d_model 512 (configs[4]): W_out is too deep for resident fragments -- both operands streamed (cad_gemm_stream), [y_f ; y_r]
+            # against [W_out, W_out] with K = 2 E; plain products for anything the kernel does not serve
+            out2d = None
+            if _STREAM_PROJ_D512 and not _LIB_OUT_X_D512 and act == torch.bfloat16:
+                out2d = ops.proj_xTw_stream(torch.cat([w_out, w_out], 1), ycat.view(2 * E, T))
+            if out2d is None:
+                out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
         wT = cache.get("wT") if cache else None
         keep = [x2d, xz, w_in, w_out, ycat]
         for i in range(2):

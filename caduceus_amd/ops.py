@@ -537,18 +537,24 @@ class _LmHead(torch.autograd.Function):
         V = w.shape[0]
         lib = L.get_lib()
         use_loss = has_labels and dloss is not None
-        if (use_loss or dlogits is not None) and hidden.dtype in (torch.float32, torch.bfloat16) and \
-                lib.cad_lm_head_bwd_supported(int(D), int(V)) and hidden.data_ptr() % 16 == 0:  # (kernel: 16-byte vector accesses)
-            # one launch on the matrix cores: softmax gradient, d hidden of both strands, dW partial slots (cad_lm_head_bwd)
+        # channel block of the kernel: the whole row (d_model 128 / 256) or 256 channels of a wider head (d_model 512: two launches,
+        # the channels are independent in both products)
+        DB = D if lib.cad_lm_head_bwd_supported(int(D), int(V)) else (256 if D % 256 == 0 and lib.cad_lm_head_bwd_supported(256, int(V)) else 0)
+        if (use_loss or dlogits is not None) and hidden.dtype in (torch.float32, torch.bfloat16) and DB and \
+                hidden.data_ptr() % 16 == 0:  # (kernel: 16-byte vector accesses)
+            # on the matrix cores: softmax gradient, d hidden of both strands, dW partial slots (cad_lm_head_bwd)
             rows = hidden.numel() // (S * D)
             dh = torch.empty_like(hidden)
             parts = torch.empty((lib.cad_lm_head_bwd_partials(rows), V, D), dtype=torch.float32, device=hidden.device)
             coef = (dloss.float() / acc[1]).reshape(1) if use_loss else None
             dlg = None if dlogits is None else dlogits.reshape(-1, V).float().contiguous()
             stream = L.stream_and_check(hidden, w, comp, lab if use_loss else None, logits, dlg, coef, dh, parts)
-            a = L.LmHeadBwdArgs(L.ptr(hidden), L.ptr(w), L.ptr(comp), L.ptr(lab) if use_loss else None, L.ptr(logits), L.ptr(dlg),
-                                L.ptr(coef), L.ptr(dh), L.ptr(parts), rows, D, V, S, int(ignore_index), L.dtype_code(hidden.dtype))
-            L.check(lib.cad_lm_head_bwd(C.byref(a), stream), "cad_lm_head_bwd")
+            for c0 in range(0, D, DB):
+                es = hidden.element_size()
+                a = L.LmHeadBwdArgs(hidden.data_ptr() + c0 * es, w.data_ptr() + c0 * 4, L.ptr(comp), L.ptr(lab) if use_loss else None,
+                                    L.ptr(logits), L.ptr(dlg), L.ptr(coef), dh.data_ptr() + c0 * es, parts.data_ptr() + c0 * 4, rows, DB, V, S,
+                                    int(ignore_index), L.dtype_code(hidden.dtype), 0 if DB == D else D)
+                L.check(lib.cad_lm_head_bwd(C.byref(a), stream), "cad_lm_head_bwd")
             return dh, parts.sum(dim=0).to(wdt), None, None, None
         # (other shapes: torch ops)
         # d loss / d logits = (softmax - onehot) * valid / count, assembled WITHOUT boolean-mask indexing: `sm[rows[valid], lab[valid]]`

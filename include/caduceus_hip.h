@@ -321,8 +321,10 @@ int cad_proj_supported(int K);
  * of LDS (ds_read_b64_tr_b16). */
 int cad_proj_wx(const cad_proj_args* a, void* stream);
 int cad_proj_wx_supported(int K, int64_t T);
-/* cad_proj_wx also takes thin M / deep K products without addend (M <= 64, K a multiple of 64 up to 1024, T % 8 == 0; ldo % 4):
- * x_proj (M = dt_rank + 2 d_state, K = d_inner; `x_proj` inside mamba_inner_fn) and d(dt_lr) = W_dt^T . d(delta). */
+/* cad_proj_wx also takes thin M / deep K products (M <= 64, K a multiple of 64 up to 1024, T % 8 == 0; ldo % 4; W (M x K) and the
+ * ring of X tiles must fit the 160 KB of LDS): x_proj (M = dt_rank + 2 d_state, K = d_inner; `x_proj` inside mamba_inner_fn) and
+ * d(dt_lr) = W_dt^T . d(delta).  Here `acc` (bf16, ldacc % 4, may alias out) is added to the fp32 sums before the one rounding: a product too
+ * deep for one W copy in LDS (x_proj at d_inner 1024: 64 x 1024) is run as two K halves, the second with the first as its addend. */
 int cad_proj_wx_thin_supported(int M, int K, int64_t T);
 /* cad_proj_wx_wgrad: the thin-M / deep-K product  out (M, T) = W (M, K) . X (K, T)  AND, from the same single pass over X, the weight
  * gradient  dW (K, M) = X (K, T) . Y (M, T)^T  -- d(dt_lr) = W_dt^T . d(delta) together with dW_dt = d(delta) . dt_lr^T of the dt_proj
@@ -453,7 +455,10 @@ int64_t cad_lm_head_partials(int64_t rows);
  *   dW[v]        = sum_t g[t][v] hidden[0,t] + sum_t g[t][comp[v]] hidden[1,t]      (comp is an involution)
  * logits as written by the forward; loss_scale = d loss / count on the device (NULL iff labels is NULL); dlogits (rows, V) fp32 or
  * NULL.  dw_partials: cad_lm_head_bwd_partials(rows) slots of (V, D) fp32, one per workgroup, WRITTEN (the caller sums them in
- * order: deterministic).  Shapes: cad_lm_head_bwd_supported (d_model 128 / 256, V <= 16); others return CAD_ERR_UNSUPPORTED. */
+ * order: deterministic).  Shapes: cad_lm_head_bwd_supported (d_model 128 / 256, V <= 16); others return CAD_ERR_UNSUPPORTED.
+ * ld (elements; 0 = D): row stride of hidden, dhidden, weight and the (V, .) rows of a dW slot -- the channels are independent in both
+ * products, so a wider head (d_model 512, configs[4]) is run as one call per block of 256 channels: D = 256, ld = 512, every pointer
+ * advanced by the block's first channel (slots then hold (V, ld) floats). */
 typedef struct {
     const void* hidden;
     const float* weight;
@@ -468,6 +473,7 @@ typedef struct {
     int D, V, n_strands;
     int64_t ignore_index;
     int dtype;
+    int64_t ld;
 } cad_lm_head_bwd_args;
 int cad_lm_head_bwd(const cad_lm_head_bwd_args* a, void* stream);
 int cad_lm_head_bwd_supported(int D, int V);

@@ -231,7 +231,7 @@ def test_embed(backend, n_strands, D):
 @pytest.mark.parametrize("V,D,B,L", [(16, 40, 2, 300), (16, 256, 2, 301), (12, 128, 1, 75), (16, 256, 1, 9000), (16, 512, 1, 200)])
 def test_lm_head_and_loss(backend, n_strands, dtype, V, D, B, L):
     """D = 40: the general kernel; D = 128 / 256: the matrix-core kernel (fp32 MFMA, 16-token tiles -- ragged last tile, a vocabulary
-    smaller than the tile, enough tiles for several per wave)."""
+    smaller than the tile, enough tiles for several per wave); D = 512: the backward as two launches over blocks of 256 channels."""
     name, dev = backend
     g = torch.Generator().manual_seed(2)
     comp = torch.tensor([0, 1, 2, 3, 4, 5, 6, 10, 9, 8, 7, 11, 12, 13, 14, 15])[:V]
@@ -367,9 +367,10 @@ def test_scan_gate_exact_zero(backend, dtype):
                                atol=tol["atol"] * max(1.0, float(z.grad[zero].abs().max())))
 
 
-@pytest.mark.parametrize("D", [40, 128])
+@pytest.mark.parametrize("D", [40, 128, 512])
 def test_lm_head_backward_without_labels(backend, D):
-    """Only an upstream gradient of the logits (no loss): cad_lm_head_bwd with labels == NULL (D = 128) / the torch path (D = 40)."""
+    """Only an upstream gradient of the logits (no loss): cad_lm_head_bwd with labels == NULL (D = 128; D = 512: two launches over blocks of
+    256 channels with the row stride 512 -- configs[4]'s head) / the torch path (D = 40)."""
     name, dev = backend
     g = torch.Generator().manual_seed(4)
     S, B, L, V = 2, 1, 333, 16

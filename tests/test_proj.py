@@ -86,6 +86,30 @@ def test_proj_wx_thin_m_deep_k(backend, M, K, T):
     assert torch.equal(outp.view(M, T // 8, 8).cpu(), out.view(M, T // 8, 8)[:, perm].cpu())
 
 
+@pytest.mark.parametrize("M,K,T", [(64, 1024, 264), (48, 256, 136)])
+def test_proj_wx_thin_m_two_k_halves(backend, M, K, T):
+    """x_proj at d_inner 1024 (configs[4]): 64 x 1024 of W_x do not fit LDS next to the X ring, so the mixer runs two K halves, the second
+    with the first as its (aliasing) addend -- fp32 sums of the half + the widened addend, rounded once.  Against the fp32 product; the halves
+    are views (row stride K of W, rows K/2.. of X), as the mixer passes them."""
+    name, dev = backend
+    W, X = (_bf(M, K, seed=31) * 0.2).to(dev), _bf(K, T, seed=32).to(dev)
+    if K == 1024:
+        assert not ops.proj_wx_supported(X, K, T, M=M)  # the case the split exists for
+    assert ops.proj_wx_supported(X, K // 2, T, M=M)
+    out = ops.proj_wx(W[:, :K // 2], X[:K // 2])
+    first = out.clone()
+    ops.proj_wx(W[:, K // 2:], X[K // 2:], out=out, acc=out)
+    ref = W.float().cpu() @ X.float().cpu()
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 4)
+    # exactly bf16(first half as stored + fp32 sums of the second half): at most one bf16 ulp from a reference assembled the same way
+    ref2 = (first.float().cpu() + W[:, K // 2:].float().cpu() @ X[K // 2:].float().cpu()).to(torch.bfloat16).float()
+    ulp = torch.maximum(ref2.abs(), torch.tensor(1e-30)) * 2.0 ** -7
+    assert bool(((out.float().cpu() - ref2).abs() <= ulp).all())
+    # a separate addend buffer gives the same bits as the aliasing one
+    out2 = ops.proj_wx(W[:, K // 2:], X[K // 2:], acc=first)
+    assert torch.equal(out2.cpu(), out.cpu())
+
+
 @pytest.mark.parametrize("M,K,T", [(512, 16, 256), (70, 24, 136)])
 def test_proj_wx_softplus_bias_epilogue(backend, M, K, T):
     """dt_proj + delta_bias + softplus in one pass (fp32 evaluation, one rounding to bf16)."""
@@ -339,6 +363,55 @@ def test_mixer_layer_bf16_production_scans_against_the_generic_fp32_path(backend
             out = engine._bimamba_tframe(hn, mf, mr, "add", True)
             monkeypatch.undo()
         out.backward(g if fast else g.float())
+        res = {k: p.grad.detach().float().cpu().clone() for k, p in params.items()}
+        res["out"], res["x"] = out.detach().float().cpu(), hn.grad.float().cpu()
+        return res
+
+    fast, ref = run(True), run(False)
+    for k in ref:
+        rel = float((fast[k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-20))
+        assert rel < 3e-2, (k, rel)
+
+
+def test_mixer_layer_d512_runs_without_a_library_gemm(backend, monkeypatch):
+    """configs[4]'s width (d_model 512: E = 1024, dt_rank 32, x_proj 64 x 1024), one weight-tied BiMamba mixer layer, bf16, forward + backward:
+    EVERY dense product of the hand-scheduled path is an own kernel -- in_proj / d(y) / out_proj / d(x2d) / dW_in / dW_out on cad_gemm_stream,
+    x_proj as two K halves of cad_proj_wx, the thin products and their weight gradients on the cad_proj_wx family -- held by making the
+    torch matrix products raise while it runs; results against the same layer on the generic fp32 path."""
+    from caduceus_amd import engine, mixer
+    from caduceus_amd.mamba import Mamba
+    name, dev = backend
+    torch.manual_seed(11)
+    D, Lq = 512, 256
+    mf, mr = Mamba(D, device=dev), Mamba(D, device=dev)
+    mr.in_proj.weight = mf.in_proj.weight
+    mr.out_proj.weight = mf.out_proj.weight
+    assert mf.d_inner == 1024 and mf.dt_rank == 32
+    hn0 = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    g = torch.randn(2, 1, Lq, D, device=dev).to(torch.bfloat16)
+    params = {tag + "." + k: v for m, tag in ((mf, "f"), (mr, "r")) for k, v in m.named_parameters()}
+
+    def boom(*a, **k):
+        raise AssertionError("a library matrix product on the d_model 512 mixer path")
+
+    def run(fast):
+        for p in params.values():
+            p.grad = None
+        hn = (hn0 if fast else hn0.float()).clone().requires_grad_(True)
+        if fast:
+            assert mixer.can_use(mf, mr, "add")
+            with monkeypatch.context() as mp:
+                for fn in ("mm", "bmm", "addmm", "matmul", "baddbmm", "einsum"):
+                    mp.setattr(torch, fn, boom)
+                mp.setattr(torch.Tensor, "__matmul__", boom)
+                mp.setattr(torch.nn.functional, "linear", boom)
+                out = mixer.bimamba_mixer(hn, mf, mr, 1)
+                out.backward(g)
+        else:
+            with monkeypatch.context() as mp:
+                mp.setattr(mixer, "can_use", lambda *a, **k: False)
+                out = engine._bimamba_tframe(hn, mf, mr, "add", True)
+            out.backward(g.float())
         res = {k: p.grad.detach().float().cpu().clone() for k, p in params.items()}
         res["out"], res["x"] = out.detach().float().cpu(), hn.grad.float().cpu()
         return res

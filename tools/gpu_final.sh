@@ -34,6 +34,8 @@ timeout 300 python bench.py --model ph --seqlen 1024 --batch 128 --cpu-sample 0 
 timeout 300 python bench.py --model ph --cpu-sample 0 > gpurun_out/bench_ph_L131072.log 2>/dev/null; tail -1 gpurun_out/bench_ph_L131072.log | cut -c1-200
 timeout 400 python bench.py --d-model 512 --seqlen 262144 --steps 3 --warmup 1 --cpu-sample 0 > gpurun_out/bench_c4shape_bf16_1gpu.log 2>/dev/null; tail -1 gpurun_out/bench_c4shape_bf16_1gpu.log | cut -c1-200
 timeout 400 python bench.py --d-model 512 --seqlen 262144 --steps 3 --warmup 1 --cpu-sample 0 --fp8-proj > gpurun_out/bench_c4shape_fp8_1gpu.log 2>/dev/null; tail -1 gpurun_out/bench_c4shape_fp8_1gpu.log | cut -c1-200
+CADUCEUS_AMD_LIB_OUT_X_PROJ_D512=1 timeout 400 python bench.py --d-model 512 --seqlen 262144 --steps 3 --warmup 1 --cpu-sample 0 --no-floor > gpurun_out/bench_c4shape_bf16_lib_out_x_proj.log 2>/dev/null; tail -1 gpurun_out/bench_c4shape_bf16_lib_out_x_proj.log | cut -c1-200
+timeout 900 bash tools/prof_step_c4.sh 2>&1 | grep -v "^W2026" | cut -c1-200 | head -8
 CADUCEUS_DP_FORCE_COLLECTIVE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --cpu-sample 0 --no-floor > gpurun_out/bench_torchrun_1rank_rccl.log 2>/dev/null; tail -1 gpurun_out/bench_torchrun_1rank_rccl.log | cut -c1-200
 timeout 300 python bench.py --global-batch 8 --steps 2 --warmup 1 --cpu-sample 0 --no-floor > gpurun_out/bench_global_batch8_1gpu.log 2>/dev/null; tail -1 gpurun_out/bench_global_batch8_1gpu.log | cut -c1-200
 fi
