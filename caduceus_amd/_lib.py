@@ -85,7 +85,12 @@ class ScanBwdArgs(C.Structure):
                 ("dA", _p), ("dB", _p), ("dC", _p), ("dD", _p), ("ddelta_bias", _p), ("SB", _i64), ("L", _i64),
                 ("split", _i64), ("E", _i), ("N", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i),
                 ("n_partials", _i), ("dhT", _p), ("dh0", _p), ("out2", _p), ("gate_fix_list", _p), ("gate_fix_count", _p),
-                ("gate_fix_dz", _p), ("delta_is_dt", _i), ("carry_only", _i)]
+                ("gate_fix_dz", _p), ("delta_is_dt", _i), ("carry_only", _i), ("fold_counters", _p)]
+
+
+class FoldArgs(C.Structure):
+    _fields_ = [("dB_slots", _p), ("dC_slots", _p), ("dB", _p), ("dC", _p), ("counters", _p), ("abort_from", _p), ("SB", _i64),
+                ("L", _i64), ("split", _i64), ("N", _i), ("n_partials", _i), ("rev_lo", _i), ("rev_hi", _i), ("dtype", _i)]
 
 
 class MlmArgs(C.Structure):
@@ -143,6 +148,9 @@ SYMBOLS = {
     "cad_reduce_partials": (_i, [_p, _i, _i64, _p, _i, _p]),
     "cad_reduce_partials_multi": (_i, [C.POINTER(ReduceJob), _i, _i, _i64, _i, _p]),
     "cad_scan_bwd_partials": (_i, [_i]),
+    "cad_fold_partials_stream": (_i, [C.POINTER(FoldArgs), _i, _i, _p]),
+    "cad_fold_stream_supported": (_i, [_i, _i, _i64, _i]),
+    "cad_scan_bwd_chunk_len": (_i64, []),
     "cad_scan_bwd_gate_fix": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_scan_gate_fix_entries": (_i64, [_i, _i64, _i64]),
     "cad_proj_wxT": (_i, [C.POINTER(ProjArgs), _p]),

@@ -162,6 +162,42 @@ __device__ __forceinline__ void cad_nt_store(V* p, V v) {
     __builtin_nontemporal_store(v, p);
 }
 
+// ---- hand-off between workgroups of DIFFERENT, concurrently running kernels (the dB / dC fold behind the scan backward) --------------
+// The per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  The valid write-through form used here:
+// producer = sc1 (write-through) 16-byte stores, every storing wave drains them (s_waitcnt vmcnt(0)), workgroup barrier, ONE relaxed
+// agent-scope atomic on the counter; consumer = ONE lane polls the counter with relaxed agent-scope loads, workgroup barrier, sc1 loads
+// of the payload (never plain loads: an L1 / L2 line of the slot may predate the producer's store).
+__device__ __forceinline__ void cad_store16_wt(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// four write-through-coherent 16-byte loads, all in flight together, then the wait (the compiler does not see asm loads: the wait is
+// part of the statement).  Scalar base + 32-bit per-lane byte offset: 1 address VGPR for the four loads -- the fold kernel that uses
+// them has to fit into the 48 VGPRs two resident scan waves leave on a SIMD.
+__device__ __forceinline__ void cad_load16x4_wt(const void* const (&base)[4] /* wave-uniform */, uint32_t voff, u32x4 (&v)[4]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, %5 sc1\n\t"
+        "global_load_dwordx4 %1, %4, %6 sc1\n\t"
+        "global_load_dwordx4 %2, %4, %7 sc1\n\t"
+        "global_load_dwordx4 %3, %4, %8 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(voff), "s"(base[0]), "s"(base[1]), "s"(base[2]), "s"(base[3])
+        : "memory");
+}
+__device__ __forceinline__ void cad_counter_add_agent(int* p, int v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int cad_counter_load_agent(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifndef CAD_POLL_SLEEP
+#define CAD_POLL_SLEEP 32
+#endif
+__device__ __forceinline__ void cad_poll_sleep() { __builtin_amdgcn_s_sleep(CAD_POLL_SLEEP); }  // 64 cycles per unit
+__device__ __forceinline__ uint64_t cad_wall_clock() { return wall_clock64(); }             // constant-rate counter
+__device__ __forceinline__ uint64_t cad_wall_clock_hz() { return 100000000ull; }            // 100 MHz on gfx9 (s_memrealtime)
+
 // more than 64 KB of dynamic LDS has to be requested per kernel: the largest size asked for so far is remembered per call site (= per
 // kernel instantiation) AND per device, so a later launch with a larger size (or on another GPU of the same process) raises it again
 #define CAD_BIG_LDS(kern, bytes)                                                                                     \

@@ -91,6 +91,20 @@ static_assert(SC_S_BWD == 8, "the backward scan is written for 8 items per lane 
 #endif
 static_assert(SC_W == 4 || SC_W == 8, "staging needs >= 256 threads; the flush mapping is written for 256 / 512");
 
+// The dB / dC partial-slot stores of the production (packed, vector) kernel: write-through (sc1), which is what lets a fold kernel on
+// another stream read them while this launch still runs -- and they are never read again by THIS kernel, so nothing is lost when the
+// line leaves the XCD's L2.  -DSC_BWD_SLOT_WT=0: plain stores (A/B switch; the concurrent fold then must not be used).
+#ifndef SC_BWD_SLOT_WT
+#define SC_BWD_SLOT_WT 1
+#endif
+__device__ __forceinline__ void sc_slot_store16(void* p, u32x4 v) {
+#if SC_BWD_SLOT_WT
+    cad_store16_wt(p, v);
+#else
+    *(u32x4*)p = v;
+#endif
+}
+
 __device__ __forceinline__ f32x2 wave_sum2(f32x2 v) { return f2(wave_sum_dpp(v[0]), wave_sum_dpp(v[1])); }
 
 // sigmoid(raw delta) recovered from dt = softplus(raw delta): 1 - exp(-dt).  Results that are rounded to bf16 take the two-term series
@@ -115,7 +129,7 @@ __device__ __forceinline__ float sc_sigmoid_from_dt(float dt) {
 // epilogue (round 5): a lane outside the row is silenced by dt = 0 and dy = 0 alone (every contribution vanishes by arithmetic, no
 // per-item select), direction + widening of an item is one v_perm_b32, dt comes from the (dt, dt u) pairs (the raw delta vector is dead
 // after the prologue), the accumulators start from the first pair's products instead of zeros, and dA is summed inside 8-lane groups per
-// pair-step and across the groups once per kernel.  Static count of a 512-position chunk: see profiles/r05_scan_isa_mix.txt.
+// pair-step and across the groups once per kernel.  Static count of a 512-position chunk: profiles/r05_scan_isa.json (tools/isa_mix.py).
 template <typename T, bool VEC, bool CO, int NPC = 0, bool ISDT = false>
 __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets sets) {
     CAD_DYN_SMEM(float, smem);  // [2 buffers][B,C][TILE] inputs, then [2 buffers][wave][dB,dC][ACC_TILE] contributions
@@ -170,6 +184,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     const int64_t part_stride = (int64_t)N * SB * L;
     T* dBg = (T*)a.dB + (int64_t)blockIdx.x * part_stride;  // this workgroup's partial-sum slot
     T* dCg = (T*)a.dC + (int64_t)blockIdx.x * part_stride;
+    // concurrent fold (cad_fold_partials_stream on another stream, include/caduceus_hip.h): one arrival per (row, chunk) and workgroup,
+    // published once every slot store of the chunk has left the CU
+    int* pub = (!CO && a.fold_counters) ? a.fold_counters + sb * nchunks : nullptr;
 
     StageRegs<T, SC_SV(SC_S)> st;
     StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
@@ -236,6 +253,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
         f32x2 dd[SC_S];               // (dt, dt * u) per item
         f32x2 dy2[SC_S / 2];          // dy of items (2q, 2q + 1)
         float sum_dt = 0.f;    // sum of dt over the lane's items: prod_i a_i = exp2(A2 * sum_dt)
+        // (publishing: every wave's slot stores of the previous chunk must have completed before the barrier of pair-step 0 -- the
+        // prefetching instantiations wait for vmcnt(0) here anyway, for their item vectors)
+        if constexpr (!PREF || SC_PRE_WAIT) {
+            if (pub) cad_wait_vmcnt<0>();
+        }
         if constexpr (LEAN) {
             // this chunk's vectors were fetched into LDS one chunk ago.  A lane's segment lies inside the row or outside it as a whole;
             // outside, dt = 0 and dy = 0 make every contribution of the lane vanish by arithmetic (a = 1, b = 0, g = G, dB = dC = 0,
@@ -614,6 +636,9 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             SC_TIME(9);  // staging store (waits for the tile loads)
             if (!(SC_WHATIF & 2)) __syncthreads();  // every channel has written its dB/dC; the prefetched B/C tile is visible
             SC_TIME(10);  // barrier wait
+            // the chunk processed before this one is complete in memory: all waves drained their stores at this chunk's start and have
+            // passed a barrier since (one lane of a NON-staging wave: its only counted wait is the one at the chunk start)
+            if (np == 0 && pub && c + 1 < nchunks && threadIdx.x == 64 * (SC_W - 1)) cad_counter_add_agent(pub + c + 1, 1);
             if (!PREF && np == NP - 1 && c > 0) {
                 // the item vectors of the next (earlier) chunk: issued now, they land behind this pair's flush and the
                 // chunk epilogue instead of stalling the next chunk's start
@@ -659,11 +684,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                             if (rev) {
                                 o[0] = cad_pack_bf16x2_safe(d1[3], d1[2]), o[1] = cad_pack_bf16x2_safe(d1[1], d1[0]);
                                 o[2] = cad_pack_bf16x2_safe(d0[3], d0[2]), o[3] = cad_pack_bf16x2_safe(d0[1], d0[0]);
-                                *(u32x4*)(grow + (L - p - SC_S)) = o;
+                                sc_slot_store16(grow + (L - p - SC_S), o);
                             } else {
                                 o[0] = cad_pack_bf16x2_safe(d0[0], d0[1]), o[1] = cad_pack_bf16x2_safe(d0[2], d0[3]);
                                 o[2] = cad_pack_bf16x2_safe(d1[0], d1[1]), o[3] = cad_pack_bf16x2_safe(d1[2], d1[3]);
-                                *(u32x4*)(grow + p) = o;
+                                sc_slot_store16(grow + p, o);
                             }
                         }
                     } else {
@@ -737,6 +762,11 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
             SC_TIME(11);  // next chunk's loads issued + flush
         }
         if constexpr (PREF && !CO) chunk_epilogue();
+    }
+    if (pub) {  // the last chunk (c = 0)
+        cad_wait_vmcnt<0>();
+        __syncthreads();
+        if (threadIdx.x == 64 * (SC_W - 1)) cad_counter_add_agent(pub, 1);
     }
     if (a.dh0 && act && lane < NP) {  // gradient w.r.t. the state entering the row
         float* gp = a.dh0 + ((int64_t)e * SB + sb) * N + 2 * lane;
@@ -879,18 +909,27 @@ template <typename T>
 __global__ void reduce_partials_kernel(const T* src, int nparts, int64_t n, T* dst, int vec) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        // (the library's one summation order, include/caduceus_hip.h: groups of CAD_FOLD_GROUP consecutive slots, then the group sums)
         if (vec && i + 4 <= n) {
             float s[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < nparts; ++k) {
-                float x[4];
-                ld4p<T>(src + (int64_t)k * n + i, x);
-                s[0] += x[0], s[1] += x[1], s[2] += x[2], s[3] += x[3];
+            for (int k0 = 0; k0 < nparts; k0 += CAD_FOLD_GROUP) {
+                float g[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = k0; k < nparts && k < k0 + CAD_FOLD_GROUP; ++k) {
+                    float x[4];
+                    ld4p<T>(src + (int64_t)k * n + i, x);
+                    g[0] += x[0], g[1] += x[1], g[2] += x[2], g[3] += x[3];
+                }
+                s[0] += g[0], s[1] += g[1], s[2] += g[2], s[3] += g[3];
             }
             cad_cvt_store<T, 4>(dst + i, s);
         } else {
             for (int64_t q = i; q < n && q < i + 4; ++q) {
                 float acc = 0.f;
-                for (int k = 0; k < nparts; ++k) acc += to_f32(src[(int64_t)k * n + q]);
+                for (int k0 = 0; k0 < nparts; k0 += CAD_FOLD_GROUP) {
+                    float g = 0.f;
+                    for (int k = k0; k < nparts && k < k0 + CAD_FOLD_GROUP; ++k) g += to_f32(src[(int64_t)k * n + q]);
+                    acc += g;
+                }
                 dst[q] = from_f32<T>(acc);
             }
         }
@@ -909,12 +948,194 @@ __global__ void reduce_partials_multi_kernel(ReduceJobs jobs, int nparts, int64_
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {  // (n % 4 == 0, 16-byte aligned: checked)
         float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < nparts; ++k) {
-            float x[4];
-            ld4p<T>(src + (int64_t)k * n + i, x);
-            s[0] += x[0], s[1] += x[1], s[2] += x[2], s[3] += x[3];
+        for (int k0 = 0; k0 < nparts; k0 += CAD_FOLD_GROUP) {
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = k0; k < nparts && k < k0 + CAD_FOLD_GROUP; ++k) {
+                float x[4];
+                ld4p<T>(src + (int64_t)k * n + i, x);
+                g[0] += x[0], g[1] += x[1], g[2] += x[2], g[3] += x[3];
+            }
+            s[0] += g[0], s[1] += g[1], s[2] += g[2], s[3] += g[3];
         }
         cad_cvt_store<T, 4>(dst + i, s);
+    }
+}
+
+// ---- the dB / dC fold behind a RUNNING scan backward (cad_fold_partials_stream, include/caduceus_hip.h) -----------------------------
+// One workgroup per (slice x of a chunk, row, parameter set), 256 threads.  A 512-position chunk of a row's dB / dC is 2 N rows x 512
+// bf16; slice x is elements [x EPW, (x + 1) EPW) of it, EPW = 2 N 512 / n_partials (256 at configs[2]: half a row).  Per slot the
+// slice is VPS = EPW / 8 16-byte vectors; thread t owns vector t % VPS of the CAD_FOLD_GROUP = 8 slots of group t / VPS (8 loads in
+// flight per thread, 32 KB per workgroup), sums them in slot order, and the first VPS threads add the group sums in group order
+// through LDS: the library's one summation order, bit-identical to cad_reduce_partials_multi.  Chunks are taken in the order the scan
+// produces them (last logical chunk first); a right-to-left row's logical chunk c lies at physical positions L - (c + 1) 512.
+#define FOLD_T 256
+#define FOLD_CHUNK 512
+struct FoldSets {
+    cad_fold_args s[SC_MAXSETS];
+};
+#define FOLD_MAX_ITEMS 256  // items (slice, row, set) one workgroup may be given
+#ifndef FOLD_WAKE_DIV
+#define FOLD_WAKE_DIV 4
+#endif
+__global__ __launch_bounds__(FOLD_T) void fold_stream_kernel(FoldSets sets, int nsets, int mode, uint64_t budget_ticks) {
+    // One launch has AT MOST one workgroup per CU (the host passes the CU count as the grid limit): a second resident fold workgroup would
+    // take the registers the next scan workgroup needs on that CU (2 x 232 + 2 x 48 > 512 VGPRs per SIMD) and starve the scan of launches
+    // with more workgroups than CUs (configs[4]: measured +19 % per layer with one fold workgroup per item).  Items beyond the grid are
+    // taken by the same workgroups, item = blockIdx.x + j gridDim.x -- in the order the scan's workgroups are dispatched, and never
+    // blocking on one item while another has a chunk ready.
+    __shared__ float part[FOLD_T * 8];
+    __shared__ int nextc[FOLD_MAX_ITEMS];  // next chunk of item j (chunks are taken from the last logical one down); < 0: done
+    __shared__ int pick_s[2];              // {item to fold now or -1, give up}
+    const int t = threadIdx.x;
+    const cad_fold_args& a0 = sets.s[0];
+    const int G = a0.n_partials, N = a0.N;
+    const int64_t L = a0.L, SB = a0.SB;
+    const int64_t nchunks = L / FOLD_CHUNK;
+    const int total = G * (int)SB * nsets;
+    const int nitems = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int EPW = 2 * N * FOLD_CHUNK / G, VPS = EPW / 8, NG = G / CAD_FOLD_GROUP;  // NG x VPS = 16 N threads work (all 256 at d_state 16)
+    const bool active = t < NG * VPS;
+    const int v = t % VPS, grp = active ? t / VPS : 0;
+    const int64_t part_stride = (int64_t)N * SB * L;
+    auto item_set = [&](int j) { return (blockIdx.x + j * gridDim.x) / (G * (int)SB); };
+    auto item_row = [&](int j) { return ((blockIdx.x + j * gridDim.x) / G) % (int)SB; };
+    auto item_slice = [&](int j) { return (blockIdx.x + j * gridDim.x) % G; };
+    auto abort_slot = [&](int j) -> int* {
+        const cad_fold_args& a = sets.s[item_set(j)];
+        return a.abort_from ? a.abort_from + (int64_t)item_row(j) * G + item_slice(j) : nullptr;
+    };
+    for (int j = t; j < nitems; j += FOLD_T) {
+        int c = (int)nchunks - 1;
+        if (mode == CAD_FOLD_CLEANUP) {  // what a concurrent pass left (stored as chunk + 1: 0 = nothing)
+            int* as = abort_slot(j);
+            c = (as ? *as : 0) - 1;
+            if (as) *as = 0;
+        }
+        nextc[j] = c;
+    }
+    __syncthreads();
+    int first = 0;  // (thread 0 only) items before `first` are done
+    uint64_t t_last = (mode == CAD_FOLD_CONCURRENT && t == 0) ? cad_wall_clock() : 0;
+    // Polling costs the scan next door (every poll is a load through the CU's memory pipeline that its staging waves wait on: same-box
+    // A/B, layer 7.60 -> 7.49 ms with 4x longer sleeps): thread 0 learns the cadence of the arrivals (a chunk every ~13 us) and sleeps
+    // through most of the predicted gap after a fold -- one or two failed polls per chunk instead of five to ten.
+    uint64_t period = 0;       // ticks between the last two picks that had to wait (0: unknown)
+    uint64_t t_wake = 0;       // do not poll before this time
+    for (;;) {
+        // ---- choose: the first item (in dispatch order) whose next chunk is complete; at most 4 pending items are polled per round
+        if (t == 0) {
+            int pick = -1, give_up = 0, alive = 0;
+            while (first < nitems && nextc[first] < 0) ++first;
+            bool waited = false;
+            for (;;) {
+                if (mode == CAD_FOLD_CONCURRENT && t_wake) {
+                    while (cad_wall_clock() < t_wake) cad_poll_sleep();
+                    t_wake = 0;
+                }
+                int polled = 0;
+                alive = 0;
+                for (int j = first; j < nitems && pick < 0 && polled < 4; ++j) {
+                    const int c = nextc[j];
+                    if (c < 0) continue;
+                    alive = 1;
+                    if (mode != CAD_FOLD_CONCURRENT) {
+                        pick = j;
+                    } else {
+                        const cad_fold_args& a = sets.s[item_set(j)];
+                        ++polled;
+                        if (cad_counter_load_agent(a.counters + (int64_t)item_row(j) * nchunks + c) >= G) pick = j;
+                    }
+                }
+                if (pick >= 0 || !alive) break;
+                if (cad_wall_clock() - t_last >= budget_ticks) {  // no arrival anywhere for the whole budget: not co-scheduled with a
+                    give_up = 1;                                  // progressing scan -- leave the rest to the cleanup launch
+                    break;
+                }
+                waited = true;
+                cad_poll_sleep();
+            }
+            if (pick >= 0 && mode == CAD_FOLD_CONCURRENT) {
+                const uint64_t now = cad_wall_clock();
+                if (waited) {  // steady state: this chunk arrived while we were watching -- the next one is a period away
+                    if (t_last) period = now - t_last;
+                    if (period > 5000) period = 5000;           // (50 us: never sleep long on a stale estimate)
+                    t_wake = now + period - period / FOLD_WAKE_DIV;  // wake a fraction of the period early
+                }
+                t_last = now;
+            }
+            pick_s[0] = pick, pick_s[1] = give_up;
+        }
+        __syncthreads();
+        const int j = cad_uniform(pick_s[0]);  // (workgroup-uniform: everything derived from the item stays in scalar registers)
+        if (j < 0) {
+            if (pick_s[1]) {
+                for (int q = t; q < nitems; q += FOLD_T) {
+                    int* as = abort_slot(q);
+                    if (nextc[q] >= 0 && as) *as = nextc[q] + 1;
+                }
+            }
+            return;  // everything folded, or given up
+        }
+        const int64_t c = cad_uniform(nextc[j]);
+        // ---- fold chunk c of item j
+        const cad_fold_args& a = sets.s[item_set(j)];
+        const int x = item_slice(j);
+        const int64_t sb = item_row(j);
+        const int e0 = x * EPW + v * 8, r = e0 / FOLD_CHUNK, p = e0 % FOLD_CHUNK;
+        const int ten = cad_uniform((x * EPW) / (N * FOLD_CHUNK));  // a slice (EPW divides N 512) never straddles the two tensors: per WORKGROUP
+        const int n = r % N;
+        const int rev = sb < a.split ? a.rev_lo : a.rev_hi;
+        const int64_t cphys = rev ? L - (c + 1) * FOLD_CHUNK : c * FOLD_CHUNK;
+        // element offsets inside one tensor's slots fit 32 bits (the launcher checks n_partials N SB L 2 < 2^32): lane arithmetic in 32 bits
+        const uint32_t row_off = ((uint32_t)n * (uint32_t)SB + (uint32_t)sb) * (uint32_t)L + (uint32_t)p + (uint32_t)cphys;
+        // slot k of the lane's group at (workgroup-uniform base of the tensor + k part_stride, scalar registers) + a 32-bit lane offset
+        const char* tbase = (const char*)(ten ? a.dC_slots : a.dB_slots);
+        const uint32_t voff = ((uint32_t)(grp * CAD_FOLD_GROUP) * (uint32_t)part_stride + row_off) * 2u;
+        char* dbase = (char*)(ten ? a.dC : a.dB);
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // two rounds of four loads: 16 data registers instead of 32
+                const void* base[4];
+                u32x4 w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) base[k] = tbase + (int64_t)(4 * h + k) * part_stride * 2;
+                cad_load16x4_wt(base, voff, w);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s[2 * q] += cad_bits2f(w[k][q] << 16);
+                        s[2 * q + 1] += cad_bits2f(w[k][q] & 0xffff0000u);
+                    }
+                }
+                // the sums of this round exist before the next round's loads are issued (otherwise the scheduler hoists those loads
+                // and both rounds' 32 data registers are live at once: 52 instead of 40 VGPRs)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cad_order_point(s[q]);
+            }
+            if (grp > 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) part[(grp * VPS + v) * 8 + q] = s[q];
+            }
+        }
+        __syncthreads();
+        if (active && grp == 0) {
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = 0.f + s[q];  // (group 0 first: the accumulator of the group sums starts from 0)
+#pragma unroll 1
+            for (int g = 1; g < NG; ++g) {  // (not unrolled: the kernel must fit the 48 VGPRs two resident scan waves leave on a SIMD)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] += part[(g * VPS + v) * 8 + q];
+            }
+            u32x4 ov;
+            ov[0] = cad_pack_bf16x2(o[0], o[1]), ov[1] = cad_pack_bf16x2(o[2], o[3]);
+            ov[2] = cad_pack_bf16x2(o[4], o[5]), ov[3] = cad_pack_bf16x2(o[6], o[7]);
+            *(u32x4*)(dbase + row_off * 2u) = ov;
+        }
+        if (t == 0) nextc[j] = (int)c - 1;
+        __syncthreads();  // `part`, nextc and pick_s are rewritten by the next round
     }
 }
 
@@ -936,6 +1157,8 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
             CAD_CHECK_ARG(a->chunk_state && a->du && a->ddelta && a->dA && a->dB && a->dC);
         }
         CAD_CHECK_ARG(a->carry_only == sets[0].carry_only);
+        // the concurrent fold reads write-through slots: bf16, 16-byte stores of the packed flush, whole chunks
+        CAD_CHECK_ARG(a->carry_only || !a->fold_counters || cad_fold_stream_supported(a->N, a->n_partials, a->L, a->dtype));
         CAD_CHECK_ARG(a->z != nullptr || a->dz == nullptr);               // dz needs the gate; dz == NULL: not wanted here
         CAD_CHECK_ARG(a->dz == nullptr || a->out != nullptr);
         CAD_CHECK_ARG(a->out2 == nullptr || a->dz != nullptr);
@@ -954,6 +1177,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
                        (uintptr_t)sets[i].du | (uintptr_t)sets[i].ddelta | (uintptr_t)sets[i].dz | (uintptr_t)sets[i].out2 |
                        (uintptr_t)sets[i].Bm | (uintptr_t)sets[i].Cm | (uintptr_t)sets[i].dB | (uintptr_t)sets[i].dC) %
                       16) == 0;
+    for (int i = 0; i < nsets; ++i) CAD_CHECK_ARG(sets[i].carry_only || !sets[i].fold_counters || vec);  // (16-byte write-through slot stores)
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
     const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
@@ -963,12 +1187,16 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     const size_t slab_floats = a->carry_only ? 0 : (packed ? 2 * PK_BUF : SC_SLAB_BUFS * ACC_BUF);
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + slab_floats) * sizeof(float) +
                          (pref ? PRE_BYTES : 0);
+    // The lean production instantiation (ISDT) exists only in builds whose tuning defines allow it (its static_assert: LDS-DMA prefetch,
+    // packed slab, 8-wave workgroups, unrolled pair loop): in every other variant build (-DSC_BWD_PREFETCH=0, -DSC_SLAB_PACKED=0, -DSC_W_BWD=4,
+    // -DSC_BWD_UNROLL_NP=0, -DSC_BWD_LEAN=0) the template argument below is `false` and the branch is the unrolled round-4 kernel again.
+    constexpr bool kLeanBuild = SC_BWD_LEAN && (SC_BWD_UNROLL_NP != 0) && SC_BWD_PREFETCH && SC_SLAB_PACKED && SC_W == 8 && SC_SLAB_BUFS == 2;
 #define SC_BWD_LAUNCH(T, V)                                                                  \
     do {                                                                                     \
-        if (SC_BWD_UNROLL_NP && SC_BWD_LEAN && !a->carry_only && V && sizeof(T) == 2 && pref && all_dt &&   \
+        if (kLeanBuild && SC_BWD_UNROLL_NP && !a->carry_only && V && sizeof(T) == 2 && pref && all_dt &&   \
             a->N == 2 * SC_BWD_UNROLL_NP) {                                                  \
-            SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2>), shmem);             \
-            CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, V && sizeof(T) == 2>), grid, block, shmem, stream, ks); \
+            SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, kLeanBuild && V && sizeof(T) == 2>), shmem);             \
+            CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP, kLeanBuild && V && sizeof(T) == 2>), grid, block, shmem, stream, ks); \
         } else if (SC_BWD_UNROLL_NP && !a->carry_only && V && sizeof(T) == 2 && a->N == 2 * SC_BWD_UNROLL_NP) { \
             SC_BIG_LDS((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP>), shmem);             \
             CAD_LAUNCH((scan_bwd_kernel<T, V, false, SC_BWD_UNROLL_NP>), grid, block, shmem, stream, ks); \
@@ -1018,6 +1246,51 @@ extern "C" int cad_scan_bwd_gate_fix(const cad_scan_bwd_args* sets, int nsets, v
         else
             return CAD_ERR_UNSUPPORTED;
     }
+    return cad_after_launch();
+}
+
+extern "C" int64_t cad_scan_bwd_chunk_len(void) { return SC_CHUNK; }
+
+extern "C" int cad_fold_stream_supported(int N, int n_partials, int64_t L, int dtype) {
+    if (dtype != CAD_BF16 || N < 1 || L < FOLD_CHUNK || L % FOLD_CHUNK != 0 || SC_CHUNK != FOLD_CHUNK) return 0;
+    if (n_partials < CAD_FOLD_GROUP || n_partials > 2048 || (n_partials & (n_partials - 1)) != 0) return 0;
+    const int elems = 2 * N * FOLD_CHUNK;
+    if (elems % n_partials != 0) return 0;
+    const int epw = elems / n_partials;
+    if (epw < 8 || epw % 8 != 0) return 0;
+    if (n_partials % CAD_FOLD_GROUP != 0) return 0;  // whole groups of 8 slots
+    const int vps = epw / 8;                         // vectors per slot and workgroup; (n_partials / 8) x vps = 16 N threads work
+    if ((n_partials / CAD_FOLD_GROUP) * vps > FOLD_T) return 0;    // d_state <= 16
+    if (FOLD_CHUNK % epw != 0 && epw % FOLD_CHUNK != 0) return 0;  // a slice lies inside one row, or covers whole rows
+    if ((N * FOLD_CHUNK) % epw != 0) return 0;                     // ... and inside one tensor
+    return SC_BWD_SLOT_WT && SC_SLAB_PACKED && SC_W == 8 && SC_SLAB_BUFS == 2;  // the write-through slot stores of the packed flush
+}
+
+extern "C" int cad_fold_partials_stream(const cad_fold_args* sets, int nsets, int mode, void* stream) {
+    CAD_CHECK_ARG(sets && nsets >= 1 && nsets <= SC_MAXSETS);
+    CAD_CHECK_ARG(mode == CAD_FOLD_CONCURRENT || mode == CAD_FOLD_CLEANUP || mode == CAD_FOLD_ALL);
+    FoldSets ks;
+    for (int i = 0; i < nsets; ++i) {
+        const cad_fold_args* a = &sets[i];
+        CAD_CHECK_ARG(a->dB_slots && a->dC_slots && a->dB && a->dC && a->SB > 0 && a->SB <= 65535);
+        CAD_CHECK_ARG(a->split >= 0 && a->split <= a->SB);
+        if (!cad_fold_stream_supported(a->N, a->n_partials, a->L, a->dtype)) return CAD_ERR_UNSUPPORTED;
+        CAD_CHECK_ARG((((uintptr_t)a->dB_slots | (uintptr_t)a->dC_slots | (uintptr_t)a->dB | (uintptr_t)a->dC) % 16) == 0);
+        if ((int64_t)a->n_partials * a->N * a->SB * a->L * 2 >= ((int64_t)1 << 32)) return CAD_ERR_UNSUPPORTED;  // 32-bit lane offsets (per tensor)
+        CAD_CHECK_ARG(mode != CAD_FOLD_CONCURRENT || (a->counters && a->abort_from));
+        CAD_CHECK_ARG(mode != CAD_FOLD_CLEANUP || a->abort_from);
+        CAD_CHECK_ARG(a->N == sets[0].N && a->n_partials == sets[0].n_partials && a->L == sets[0].L && a->SB == sets[0].SB);
+        ks.s[i] = *a;
+    }
+    for (int i = nsets; i < SC_MAXSETS; ++i) ks.s[i] = sets[0];
+    // a poll that sees no arrival for this long gives the chunk (and the rest of the row slice) to the cleanup launch: the scan produces a
+    // chunk every ~13 us, so 20 ms means "the scan is not running next to us" (serialised queues, a profiler, a debugger)
+    const uint64_t budget = 2000000ull;  // ticks of the 100 MHz wall clock
+    const int64_t items = (int64_t)sets[0].n_partials * sets[0].SB * nsets;
+    const int cus = cad_cu_count();  // one workgroup per CU at most (see the kernel)
+    if (items > (int64_t)cus * FOLD_MAX_ITEMS) return CAD_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)(items < cus ? items : cus)), block(FOLD_T);
+    CAD_LAUNCH(fold_stream_kernel, grid, block, 0, stream, ks, nsets, mode, budget);
     return cad_after_launch();
 }
 

@@ -360,13 +360,16 @@ __device__ __forceinline__ void sc_glds16(const void* gsrc, uint32_t lds_base) {
 // waves 0-3 in the DPP / packed-FMA phases, profiles/r02_phase_timing_dma_prefetch.txt, while waves 0-3 -- which also do
 // the tile staging -- idle at the barrier).
 #ifndef SC_PRIO
-#define SC_PRIO 0
+#define SC_PRIO 0   // (3 = every scan wave above the co-resident fold kernel's priority 0: -2.3 % per layer while that kernel polled every
+                    // ~0.5 us, nothing once it sleeps through the predicted gap between arrivals -- profiles/r06_ab_stream_fold.txt)
 #endif
 __device__ __forceinline__ void sc_static_priority(int wave, int nwaves) {
 #if SC_PRIO == 1 && !defined(CAD_EMU)
     if (wave >= nwaves / 2) __builtin_amdgcn_s_setprio(1);  // wave is wave-uniform (readfirstlane): a scalar branch
 #elif SC_PRIO == 2 && !defined(CAD_EMU)
     if (wave < nwaves / 2) __builtin_amdgcn_s_setprio(1);   // A/B: the staging half instead
+#elif SC_PRIO == 3 && !defined(CAD_EMU)
+    __builtin_amdgcn_s_setprio(1);  // every scan wave above the (priority 0) waves of a kernel that shares the CU: the concurrent dB / dC fold
 #endif
 }
 

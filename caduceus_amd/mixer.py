@@ -157,6 +157,10 @@ _LIB_OUT_X_D512 = os.environ.get("CADUCEUS_AMD_LIB_OUT_X_PROJ_D512", "0") == "1"
 # BASELINE configs[4]: in_proj on the fp8 (OCP e4m3) matrix cores (csrc/gemm_fp8.hip); set CADUCEUS_AMD_FP8_PROJ=1 or call
 # set_fp8_in_proj(True).  Forward only: the backward keeps the bf16 activations it saves today.
 _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
+# the dB / dC partial slots folded by cad_fold_partials_stream on a second stream WHILE the scan backward runs (the scan is bound by VALU
+# issue, the fold by memory latency: 0.39 ms per layer of fold kernel leave the critical path); CADUCEUS_AMD_STREAM_FOLD=0: the fold
+# kernel behind the scan (cad_reduce_partials_multi) -- same summation order, bit-identical gradients
+_STREAM_FOLD = os.environ.get("CADUCEUS_AMD_STREAM_FOLD", "1") != "0"
 
 
 def set_fp8_in_proj(on: bool) -> None:
@@ -206,8 +210,10 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
         alog += [mf.A_log.detach().float(), mr.A_log.detach().float()]
         owners.append((mf, ps + [mf.A_log, mr.A_log], out))
     torch._foreach_copy_(dst, src)
-    # (W_in^T feeds cad_gemm_stream's d(x2d) only: d_model <= 256 with the own tiled GEMM on)
-    need_in_T = _OWN_GEMM and "in" in stacked and (stacked["in"].shape[2] <= 256 or _OWN_GEMM_D512)
+    # (W_in^T feeds cad_gemm_stream: d(x2d) -- d_model <= 256, or 512 with the own tiled GEMM on -- and the streamed in_proj forward at
+    # d_model 512, which must not depend on the d(x2d) switches: ADVICE r5)
+    need_in_T = "in" in stacked and ((_OWN_GEMM and (stacked["in"].shape[2] <= 256 or _OWN_GEMM_D512)) or
+                                     (_STREAM_PROJ_D512 and stacked["in"].shape[2] > 256))
     trans = {kd: stacked[kd].transpose(1, 2).contiguous() for kd in ("out", "x", "dt") + (("in",) if need_in_T else ()) if kd in stacked}
     cursor = {kd: 0 for kd in kinds}
 
@@ -228,6 +234,9 @@ def prepare_step_cache(pairs, act: torch.dtype) -> None:
         tr = out.pop()  # [W_out^T, W_x_f^T, W_dt_f^T, W_x_r^T, W_dt_r^T, W_in^T]
         mf._cad_step_cache = {"versions": [(id(p), p._version) for p in ps], "w": out, "A": (negA[2 * i], negA[2 * i + 1]),
                               "wT": {"out": tr[0], "x": (tr[1], tr[3]), "dt": (tr[2], tr[4]), "in": tr[5]}}
+        if _STREAM_PROJ_D512 and not _LIB_OUT_X_D512 and out[1].shape[0] > 256:
+            # d_model 512: out_proj streams [y_f ; y_r] against [W_out, W_out] (K = 2 E) -- built once per step, not per layer call
+            mf._cad_step_cache["w_out2"] = torch.cat([out[1], out[1]], 1)
         if _FP8_IN_PROJ and act == torch.bfloat16 and ops.fp8_proj_supported(out[0], out[0].shape[1]):
             mf._cad_step_cache["w_in_fp8"] = ops.quant_weight_fp8(ps[0])  # from the fp32 master weight, once per step
 
@@ -263,8 +272,10 @@ class BiMambaMixerFn(torch.autograd.Function):
             xz = ops.proj_wxT_fp8(wq, sw, xq, sx).view(2 * E, SB, Lq)
         else:
             xz = None
-            w_inT = ((cache or {}).get("wT") or {}).get("in")
-            if _STREAM_PROJ_D512 and Dm > 256 and act == torch.bfloat16 and w_inT is not None:
+            if _STREAM_PROJ_D512 and Dm > 256 and act == torch.bfloat16:
+                w_inT = ((cache or {}).get("wT") or {}).get("in")
+                if w_inT is None:  # no step cache (eval, or parameters changed since prepare_step_cache): transpose here
+                    w_inT = w_in.t().contiguous()
                 # d_model 512: both operands streamed through the tiled kernel (A = tokens, B = W_in^T from the step cache), channel-major
                 # result (None if the shape is not served)
                 xz = ops.gemm_out_t(x2d, w_inT)
@@ -292,8 +303,9 @@ class BiMambaMixerFn(torch.autograd.Function):
             if ops.proj_wx_supported(xc, E, T, M=R + 2 * N):  # thin-M / deep-K MFMA kernel: xc read once, W_x in LDS
                 dbc = ops.proj_wx(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
             elif not _LIB_OUT_X_D512 and E % 128 == 0 and ops.proj_wx_supported(xc, E // 2, T, M=R + 2 * N):
-                # d_inner 1024 (configs[4]): 64 rows x 1024 of W_x do not fit LDS next to the X ring -- two K halves, the second with the
-                # first as its addend (fp32 sums + the widened addend, rounded once); xc is still read once
+                # d_inner 1024 (configs[4]): 64 rows x 1024 of W_x do not fit LDS next to the X ring -- two K halves.  The first half is
+                # STORED in bf16 and widened again as the addend of the second, so dt_lr / B / C see two roundings (first half, then the
+                # sum), not one fp32 accumulation over K; xc is still read once
                 dbc = ops.proj_wx(w_x[:, :E // 2], xc.view(E, T)[:E // 2])
                 ops.proj_wx(w_x[:, E // 2:], xc.view(E, T)[E // 2:], out=dbc, acc=dbc)
                 dbc = dbc.view(R + 2 * N, SB, Lq)
@@ -337,7 +349,8 @@ class BiMambaMixerFn(torch.autograd.Function):
             # against [W_out, W_out] with K = 2 E; plain products for anything the kernel does not serve
             out2d = None
             if _STREAM_PROJ_D512 and not _LIB_OUT_X_D512 and act == torch.bfloat16:
-                out2d = ops.proj_xTw_stream(torch.cat([w_out, w_out], 1), ycat.view(2 * E, T))
+                w_out2 = (cache or {}).get("w_out2")
+                out2d = ops.proj_xTw_stream(w_out2 if w_out2 is not None else torch.cat([w_out, w_out], 1), ycat.view(2 * E, T))
             if out2d is None:
                 out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
         wT = cache.get("wT") if cache else None
@@ -385,6 +398,12 @@ class BiMambaMixerFn(torch.autograd.Function):
             _, _, A_, _, Df_, bfz_, wf_, bf_ = sets[i][:8]
             zshapes += [A_.shape, Df_.shape, bfz_.shape, wf_.shape, (bf_.shape if bf_ is not None else (0,))]
         zshapes += [(1,), (1,)]  # worklist counters of the exact z == 0 gate gradient (int32 views of zero bits)
+        N0 = sets[0][2].shape[1]
+        npart0 = lib.cad_scan_bwd_partials(E)
+        stream_fold = (_STREAM_FOLD and sets[1][2].shape[1] == N0 and ops.fold_stream_supported(N0, npart0, Lq // k, act))
+        if stream_fold:  # arrival counters (set, row, chunk) and give-up records (set, row, slice) of the concurrent fold: zero bits
+            nch = (Lq // k) // int(lib.cad_scan_bwd_chunk_len())
+            zshapes += [(2, SB * k, nch), (2, SB * k, npart0)]
         zbuf = _zeros_f32(zshapes, x2d.device)
         fix_cnt = [zbuf[10].view(torch.int32), zbuf[11].view(torch.int32)]
         n_fix = lib.cad_scan_gate_fix_entries(E, SB, Lq)
@@ -410,22 +429,37 @@ class BiMambaMixerFn(torch.autograd.Function):
                                     L.ptr(y_r) if (i == 0 and _SHARED_GATE) else None, L.ptr(fix_list[i]),
                                     L.ptr(fix_cnt[i]), L.ptr(dxz[E:]) if (_SHARED_GATE or i == 0) else L.ptr(dz))
             args[i].delta_is_dt = int(fused_sp[i])
+            if stream_fold:
+                args[i].fold_counters = L.ptr(zbuf[12][i])
             work.append((du, ddelta, dA, dD, dbias, dBC, npart))
-        _keep = ops.scan_bwd_launch(lib, args, 2, stream, k, seg_P, dirs, split)
+        # the dB / dC partial slots of BOTH sets are folded straight into the rows of each set's x_proj gradient operand ...
+        ddbcs = [torch.empty_like(sets[i][3]) for i in range(2)]
+        launch_scan = lambda: ops.scan_bwd_launch(lib, args, 2, stream, k, seg_P, dirs, split)
+        if stream_fold:
+            # ... chunk by chunk on a second stream while the scan still runs (cad_fold_partials_stream)
+            fargs = (L.FoldArgs * 2)()
+            for i in range(2):
+                N_, R_ = sets[i][2].shape[1], sets[i][3].shape[0] - 2 * sets[i][2].shape[1]
+                dBC_ = work[i][5]
+                fargs[i] = L.FoldArgs(L.ptr(dBC_[0]), L.ptr(dBC_[1]), L.ptr(ddbcs[i][R_:R_ + N_]), L.ptr(ddbcs[i][R_ + N_:]),
+                                      L.ptr(zbuf[12][i]), L.ptr(zbuf[13][i]), SB * k, Lq // k, split * k, N_, work[i][6],
+                                      dirs[i][0], dirs[i][1], L.dtype_code(act))
+            _keep = ops.fold_behind_scan(lib, fargs, 2, x2d.device, launch_scan, give_ups=zbuf[13])
+        else:
+            _keep = launch_scan()
         L.check(lib.cad_scan_bwd_gate_fix(args, 2, stream), "cad_scan_bwd_gate_fix")  # no-op unless some z == 0 exactly
         grads, dxcs, part = [], [], []
-        # the dB / dC partial slots of BOTH sets are folded by one launch (four folds: cad_reduce_partials_multi), straight into the
-        # rows of each set's x_proj gradient operand
-        ddbcs = [torch.empty_like(sets[i][3]) for i in range(2)]
-        jobs = (L.ReduceJob * 4)()
-        for i in range(2):
-            N_, R_ = sets[i][2].shape[1], sets[i][3].shape[0] - 2 * sets[i][2].shape[1]
-            dBC_ = work[i][5]
-            jobs[2 * i] = L.ReduceJob(L.ptr(dBC_[0]), L.ptr(ddbcs[i][R_:R_ + N_]))
-            jobs[2 * i + 1] = L.ReduceJob(L.ptr(dBC_[1]), L.ptr(ddbcs[i][R_ + N_:]))
-        assert work[0][6] == work[1][6] and sets[0][2].shape[1] == sets[1][2].shape[1], "one fold launch: both sets share depth and d_state"
-        L.check(lib.cad_reduce_partials_multi(jobs, 4, work[0][6], sets[0][2].shape[1] * SB * Lq, L.dtype_code(act), stream),
-                "cad_reduce_partials_multi")
+        if not stream_fold:
+            # ... by one launch behind the scan (four folds: cad_reduce_partials_multi)
+            jobs = (L.ReduceJob * 4)()
+            for i in range(2):
+                N_, R_ = sets[i][2].shape[1], sets[i][3].shape[0] - 2 * sets[i][2].shape[1]
+                dBC_ = work[i][5]
+                jobs[2 * i] = L.ReduceJob(L.ptr(dBC_[0]), L.ptr(ddbcs[i][R_:R_ + N_]))
+                jobs[2 * i + 1] = L.ReduceJob(L.ptr(dBC_[1]), L.ptr(ddbcs[i][R_ + N_:]))
+            assert work[0][6] == work[1][6] and sets[0][2].shape[1] == sets[1][2].shape[1], "one fold launch: both sets share depth and d_state"
+            L.check(lib.cad_reduce_partials_multi(jobs, 4, work[0][6], sets[0][2].shape[1] * SB * Lq, L.dtype_code(act), stream),
+                    "cad_reduce_partials_multi")
         for i in range(2):
             xc, delta, A, dbc, Df, bfz, wf, bf, w_x, w_dt, state, A_log = sets[i]
             du, ddelta, dA, dD, dbias, dBC, npart = work[i]

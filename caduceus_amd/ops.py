@@ -310,6 +310,7 @@ def scan_bwd_launch(lib, args, nsets: int, stream, k: int, Ps, dirs, split: int)
             g = torch.empty((E, SBk, N), dtype=torch.float32, device=dev)
             p1[i].carry_only, p1[i].dhT, p1[i].dh0 = 1, None, L.ptr(g)
             p1[i].dz, p1[i].out2, p1[i].gate_fix_list, p1[i].gate_fix_count = None, None, None, None
+            p1[i].fold_counters = None  # (the carry pass writes no slots)
             gs.append(g)
         L.check(lib.cad_scan_bwd_multi(p1, nsets, stream), "cad_scan_bwd_multi (carry pass)")
         for i in range(nsets):
@@ -318,6 +319,48 @@ def scan_bwd_launch(lib, args, nsets: int, stream, k: int, Ps, dirs, split: int)
             keep.append(dhT)
     L.check(lib.cad_scan_bwd_multi(args, nsets, stream), "cad_scan_bwd_multi")
     return keep
+
+
+# ---- the dB / dC fold behind the running scan backward (cad_fold_partials_stream) ----------------------------------------------------
+_FOLD_SIDE = {}  # device index -> (side stream, "inputs ready" event, "fold done" event)
+
+
+def fold_stream_supported(N: int, npart: int, Lq: int, dtype) -> bool:
+    return bool(L.get_lib().cad_fold_stream_supported(int(N), int(npart), int(Lq), L.dtype_code(dtype)))
+
+
+def _fold_side(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _FOLD_SIDE:
+        _FOLD_SIDE[key] = (torch.cuda.Stream(device), torch.cuda.Event(), torch.cuda.Event())
+    return _FOLD_SIDE[key]
+
+
+FOLD_GIVE_UPS = None  # a list: every device launch appends the number of give-up records (a device scalar) of its concurrent pass
+
+
+def fold_behind_scan(lib, fold_args, nsets: int, device, launch_scan, give_ups=None):
+    """launch_scan() enqueues cad_scan_bwd_multi (with fold_counters set) on the current stream; the fold is enqueued on a second stream
+    right behind it so that the two kernels run side by side (the fold's workgroups -- 48 VGPRs, 8 KB of LDS -- fit on the CUs next to
+    the scan's), the current stream then waits for the fold and runs the cleanup pass (a no-op unless the fold gave up waiting, i.e.
+    the two kernels were NOT co-scheduled).  The host emulator has no streams: the same three launches in order."""
+    if not L.is_device_build():
+        out = launch_scan()
+        L.check(lib.cad_fold_partials_stream(fold_args, nsets, 0, None), "cad_fold_partials_stream (concurrent)")
+        L.check(lib.cad_fold_partials_stream(fold_args, nsets, 1, None), "cad_fold_partials_stream (cleanup)")
+        return out
+    side, ev_ready, ev_done = _fold_side(device)
+    main = torch.cuda.current_stream(device)
+    ev_ready.record(main)  # counters zeroed, slots and destination rows allocated (and their previous users finished) before the fold starts
+    out = launch_scan()
+    side.wait_event(ev_ready)
+    L.check(lib.cad_fold_partials_stream(fold_args, nsets, 0, C.c_void_p(side.cuda_stream)), "cad_fold_partials_stream (concurrent)")
+    ev_done.record(side)
+    main.wait_event(ev_done)
+    if FOLD_GIVE_UPS is not None and give_ups is not None:  # diagnostics (tests, tools): slices the concurrent pass left to the cleanup
+        FOLD_GIVE_UPS.append(torch.count_nonzero(give_ups))
+    L.check(lib.cad_fold_partials_stream(fold_args, nsets, 1, C.c_void_p(main.cuda_stream)), "cad_fold_partials_stream (cleanup)")
+    return out
 
 
 def gate_fix_buffers(lib, u, N):

@@ -268,6 +268,11 @@ typedef struct {
                         * (exp, C * dy, one chain per item and state); no other output is written, B / chunk_state / out are
                         * not read (du, ddelta, dA, dB, dC, dD, ddelta_bias, chunk_state may be NULL).  Pass 1 of an L-split
                         * backward (see map_only). */
+    int* fold_counters; /* optional (NULL = absent): (SB, ceil(L / cad_scan_bwd_chunk_len())) int32, zeroed by the caller.  When given, the
+                        * dB / dC slot stores go out write-through and every workgroup adds 1 to counter [row][chunk] once ALL its
+                        * slot stores of that 512-position chunk have left the CU, so that cad_fold_partials_stream -- launched on ANOTHER
+                        * stream while this kernel runs -- can fold chunk by chunk behind it (a chunk is complete at
+                        * n_partials arrivals).  Ignored by a carry_only pass. */
 } cad_scan_bwd_args;
 int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream);
 int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void* stream);
@@ -284,6 +289,44 @@ typedef struct {
     void* dst;
 } cad_reduce_job;
 int cad_reduce_partials_multi(const cad_reduce_job* jobs, int njobs, int n_partials, int64_t n, int dtype, void* stream);
+/* Summation order of every fold of this library (cad_reduce_partials, _multi, cad_fold_partials_stream): the slots are summed in groups of
+ * CAD_FOLD_GROUP consecutive slots (left to right inside a group, from 0), the group sums are added left to right -- one fixed order, so a
+ * gradient does not depend on WHICH of the three folded it.
+ *
+ * cad_fold_partials_stream: the same fold of the dB / dC slots of a scan backward, chunk by chunk WHILE cad_scan_bwd_multi still runs (the
+ * reference reduces dB / dC over the channels inside selective_scan_cuda.bwd itself, modeling_caduceus.py:11,128,130).  The scan
+ * backward is bound by VALU issue and leaves ~85 % of the memory bandwidth idle; its partial slots (2.15 GB per configs[2] layer) used
+ * to be re-read by a fold kernel AFTER it (0.39 ms per layer).  Launched on a second stream right after the scan, this kernel's
+ * workgroups (one per slice of a chunk: 256 threads, < 64 VGPRs, 8 KB of LDS -- they fit on the CUs next to the scan's) poll the
+ * scan's fold_counters and fold a chunk as soon as all n_partials producers have published it: the fold ends a few microseconds after
+ * the scan.  Visibility across the non-coherent per-XCD L2s follows the write-through recipe: sc1 slot stores, every storing wave
+ * drains (s_waitcnt vmcnt(0)), workgroup barrier, one relaxed agent-scope counter increment; the consumer polls with one lane
+ * (relaxed agent-scope load), workgroup barrier, sc1 loads.
+ * mode CAD_FOLD_CONCURRENT: poll, with a bounded wait -- a workgroup whose chunk does not complete within the budget records (chunk + 1) in
+ * abort_from[row][slice] and returns (never a hang: if the two kernels are not co-scheduled the fold simply runs after the scan, when
+ * every counter is complete).  mode CAD_FOLD_CLEANUP (same stream as the consumers, after both kernels): folds what a concurrent
+ * launch left (abort_from > 0), without polling; returns at once otherwise.  mode CAD_FOLD_ALL: no polling, everything (test / fallback).
+ * bf16, L % 512 == 0, n_partials a power of two in 8 .. 2048 with 2 N 512 / n_partials >= 8 (cad_fold_stream_supported). */
+#define CAD_FOLD_GROUP 8
+#define CAD_FOLD_CONCURRENT 0
+#define CAD_FOLD_CLEANUP 1
+#define CAD_FOLD_ALL 2
+typedef struct {
+    const void* dB_slots;   /* (n_partials, N, SB, L) as written by cad_scan_bwd_multi */
+    const void* dC_slots;
+    void* dB;               /* (N, SB, L) */
+    void* dC;
+    const int* counters;    /* the scan's fold_counters (CAD_FOLD_CONCURRENT) */
+    int* abort_from;        /* (SB, n_partials) int32, zeroed by the caller: CAD_FOLD_CONCURRENT stores (chunk + 1) where a slice gave up,
+                             * CAD_FOLD_CLEANUP folds chunks chunk .. 0 of such a slice and clears the entry; 0 = nothing left */
+    int64_t SB, L, split;
+    int N, n_partials;
+    int rev_lo, rev_hi;
+    int dtype;
+} cad_fold_args;
+int cad_fold_partials_stream(const cad_fold_args* sets, int nsets, int mode, void* stream);
+int cad_fold_stream_supported(int N, int n_partials, int64_t L, int dtype);
+int64_t cad_scan_bwd_chunk_len(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Dense projections of the mixer on the matrix cores (bf16 MFMA, fp32 accumulation).   Replace the `in_proj` /

@@ -176,6 +176,20 @@ template <typename V>
 __device__ __forceinline__ void cad_nt_store(V* p, V v) {
     *p = v;
 }
+// hand-off primitives of the concurrent dB / dC fold: launches are synchronous here (a consumer kernel only ever runs after its
+// producer has finished), so write-through stores / loads are plain ones and the poll sees the final counts at once
+__device__ __forceinline__ void cad_store16_wt(void* p, u32x4 v) { *(u32x4*)p = v; }
+__device__ __forceinline__ void cad_load16x4_wt(const void* const (&base)[4], uint32_t voff, u32x4 (&v)[4]) {
+    for (int i = 0; i < 4; ++i) v[i] = *(const u32x4*)((const char*)base[i] + voff);
+}
+__device__ __forceinline__ void cad_counter_add_agent(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+__device__ __forceinline__ int cad_counter_load_agent(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void cad_poll_sleep() {}
+__device__ __forceinline__ uint64_t cad_wall_clock() {
+    static uint64_t t = 0;  // every call "takes" 1 ms: a poll that does not succeed runs out of its budget after a few calls
+    return __atomic_add_fetch(&t, 100000, __ATOMIC_RELAXED);
+}
+__device__ __forceinline__ uint64_t cad_wall_clock_hz() { return 100000000ull; }
 #define CAD_BIG_LDS(kern, bytes) (void)0
 
 static inline float cad_e4m3_to_f32(uint8_t v) {

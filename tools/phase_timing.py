@@ -11,6 +11,7 @@ import sys
 
 import torch
 
+os.environ.setdefault("CADUCEUS_AMD_ALLOW_TIMING_BUILD", "1")  # the loader refuses -DSC_TIMING libraries as the product (caduceus_amd/_lib.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from caduceus_amd import ops, _lib  # noqa: E402
 
