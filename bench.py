@@ -402,11 +402,13 @@ def main():
     _lib.prof_reset()
     _lib.prof_enable(True, kinds=("scan_fwd", "scan_bwd"))
     reducer.time_exposed = use_dist  # two event records per step: how long the compute stream waits for all-reduces backward did not hide
+    ar0 = reducer.allreduces_launched
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    ar_timed = reducer.allreduces_launched - ar0
     reducer.time_exposed = False
     exposed = reducer.exposed_ms()
     _lib.prof_enable(False)
@@ -426,6 +428,8 @@ def main():
     dist_info = {"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
                  "collective_library": None, "grad_allreduce_bytes_per_step": sum(b.numel() * 4 for b in reducer.buckets),
                  "buckets": len(reducer.buckets),
+                 # collectives per optimizer step, counted: = buckets (accumulation micro-steps run under no_sync())
+                 "allreduces_per_step": ar_timed / max(1, args.steps),
                  # MAX over ranks of the mean time the compute stream spent inside reducer.finish(): the part of the gradient
                  # all-reduce that backward did not hide (+ the launch of late buckets); null without a process group
                  "allreduce_exposed_ms_per_step": exposed_ms if use_dist else None}

@@ -798,6 +798,23 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
 // and 4 B fragments through the transposing read (B rows are k, columns contiguous) and issues 32 MFMAs.  Both operands cross HBM
 // once per tile row / column they belong to: the kernel is the classic tiled GEMM, written for the three shapes of the mixer
 // backward where R or C is only one or four tiles wide and everything else is the stream.
+#ifndef GS_SLICE_INTERLEAVE
+#define GS_SLICE_INTERLEAVE 0   // measured: 0.303 vs 0.249 ms (neighbouring workgroups on neighbouring 64-byte pieces is WORSE)
+#endif
+#ifndef GS_SLICE_ROTATE
+#define GS_SLICE_ROTATE 1
+#endif
+// start chunk of (slice sl, row tile rt) = (2 sl + rt) mod chunks-per-slice: the 64 x 4 workgroups of a configs[2] weight gradient then
+// sit on all 128 chunk phases of the 8 KB every slice owns in a strided row at once.  tools/gemm_stream_bench.py, same box, ms per
+// product (library K-split bmm + sum: 0.232): no rotation 0.249 | (37, 11) 0.232 | (53, 29) 0.243 | (19, 5) 0.232 | (45, 77) 0.243 |
+// (27, 32) 0.250 | (64, 16) 0.255 | (1, 32) 0.255 | (3, 1) 0.226 | (3, 64) 0.228 | (1, 0) 0.225 | (4, 1) 0.231 | (5, 2) 0.233 |
+// (7, 3) 0.222 | (2, 1) 0.215 -- and neighbouring workgroups on neighbouring 64-byte pieces (GS_SLICE_INTERLEAVE) 0.303.
+#ifndef GS_ROT_SL
+#define GS_ROT_SL 2
+#endif
+#ifndef GS_ROT_RT
+#define GS_ROT_RT 1
+#endif
 struct GsCfg {
     static constexpr int RT = 256, CT = 256, KC = 32, RING = 4;
     static constexpr int AROW = KC * 2;               // 64 bytes per A tile row: four 16-byte pieces, piece index ^ gs_aswz(row)
@@ -866,15 +883,27 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_
     int ich = 0, islot = 0;
     int64_t iitem = i0;
     const bf16_t *iA = nullptr, *iB = nullptr;
+    // GS_SLICE_INTERLEAVE (weight-gradient mode, nslices > 1): slice s takes the 32-k chunks s, s + nslices, s + 2 nslices, ... of the
+    // reduction range instead of one contiguous k range, so that the workgroups running side by side read NEIGHBOURING 64-byte pieces of
+    // the same strided rows (one DRAM page serves them all) instead of 64 bytes each from pages 8 KB apart
+    const int64_t kstep = (GS_SLICE_INTERLEAVE && a.nslices > 1) ? (int64_t)a.nslices * C::KC : (int64_t)C::KC;
+    // GS_SLICE_ROTATE (weight-gradient mode): every (slice, row tile) starts its walk at a different chunk of its k range and wraps
+    // around.  The slices are 8 KB apart in every strided row and all workgroups advance in step, so without the rotation the whole
+    // chip reads the same 4 KB phase of every 8 KB at any moment (the order of a slice's chunks only changes fp32 rounding).
+    int irot = 0;
     auto seek = [&]() {
         int64_t rt, ct, sl;
         decode(iitem, rt, ct, sl);
-        iA = (const bf16_t*)a.A + rt * C::RT * a.lda + sl * kper;
-        iB = (const bf16_t*)a.B + sl * kper * a.ldb + ct * C::CT;
+        const int64_t kbase = (GS_SLICE_INTERLEAVE && a.nslices > 1) ? sl * C::KC : sl * kper;
+        iA = (const bf16_t*)a.A + rt * C::RT * a.lda + kbase;
+        iB = (const bf16_t*)a.B + kbase * a.ldb + ct * C::CT;
+        irot = (GS_SLICE_ROTATE && a.nslices > 1) ? (int)((sl * GS_ROT_SL + rt * GS_ROT_RT) % nk) : 0;
     };
     seek();
     auto issue_next = [&]() {
-        gs_issue_chunk(iA, a.lda, iB, a.ldb, (int64_t)ich * C::KC, smem + islot * C::STAGE, wave, lane);
+        int kc = ich + irot;
+        if (kc >= nk) kc -= nk;
+        gs_issue_chunk(iA, a.lda, iB, a.ldb, (int64_t)kc * kstep, smem + islot * C::STAGE, wave, lane);
         islot = (islot + 1) & (C::RING - 1);
         if (++ich == nk) {
             ich = 0;

@@ -67,6 +67,7 @@ class BucketedGradReducer:
         # measurement aid (bench.py): time every finish() -- on a GPU as a pair of events on the compute stream, i.e. how long that
         # stream had to wait for all-reduces that backward did NOT hide (the exposed part); on CPU as host time
         self.time_exposed = False
+        self.allreduces_launched = 0  # collectives issued so far: one per bucket and OPTIMIZER step, whatever the number of micro-steps
         self._exposed = []
 
     def _reset_counters(self):
@@ -100,6 +101,7 @@ class BucketedGradReducer:
         if self.average:
             flat.div_(self.world)
         self._handles[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.allreduces_launched += 1
 
     def _hook(self, p: torch.nn.Parameter):
         bi = self._bucket_of[id(p)]

@@ -43,6 +43,10 @@ def _run(nproc, extra, tmp_path):
     # N = 4 -> 2, global batch 8 either way
     (2, ["--global-batch", "8"], 4, "strong"),
     (4, ["--global-batch", "8"], 2, "strong"),
+    # the driver's 8-GPU lines (no 8-GPU node exists for this build: the exact launch line runs here, eight gloo ranks on the emulator):
+    # configs[3] = one sequence per rank, global batch 8 (slurm_scripts/run_pretrain_caduceus.sh:5-8,38-42)
+    (8, [], 1, "weak"),
+    (8, ["--global-batch", "8"], 1, "strong"),
 ])
 def test_bench_two_ranks_over_gloo(tmp_path, nproc, extra, accum, scaling):
     line = _run(nproc, extra, tmp_path)
@@ -56,6 +60,7 @@ def test_bench_two_ranks_over_gloo(tmp_path, nproc, extra, accum, scaling):
     d = line["dist"]
     assert d["world_size"] == nproc and d["backend"] == "gloo" and d["buckets"] >= 1 and d["grad_allreduce_bytes_per_step"] > 0
     assert d["allreduce_exposed_ms_per_step"] is not None and d["allreduce_exposed_ms_per_step"] >= 0.0
+    assert d["allreduces_per_step"] == d["buckets"]  # one collective per bucket and optimizer step, however many micro-steps
     # whole-job aggregate: tokens of ALL ranks and micro-steps over the MAX-over-ranks time
     tokens = 256 * nproc * 2 * accum
     assert abs(line["value"] - tokens / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
