@@ -163,6 +163,11 @@ _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
 _STREAM_FOLD = os.environ.get("CADUCEUS_AMD_STREAM_FOLD", "1") != "0"
 
 
+# test hook (tests/test_configs.py): a list here receives, per backward call, the operands of the x_proj weight gradient of both
+# parameter sets as the kernels saw them -- {"ddbc": [d(dt_lr ; B ; C) (R + 2N, T)] * 2, "xc": [conv output (E, T)] * 2} (clones)
+CAPTURE_XPROJ_OPERANDS = None
+
+
 def set_fp8_in_proj(on: bool) -> None:
     global _FP8_IN_PROJ
     _FP8_IN_PROJ = bool(on)
@@ -501,6 +506,9 @@ class BiMambaMixerFn(torch.autograd.Function):
                 du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))
             dxcs.append(du)
             part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
+        if CAPTURE_XPROJ_OPERANDS is not None:
+            CAPTURE_XPROJ_OPERANDS.append({"ddbc": [d.reshape(d.shape[0], T).clone() for d in ddbcs],
+                                           "xc": [sets[i][0].reshape(E, T).clone() for i in range(2)]})
         conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs,
                             bufs=[(zbuf[5 * i + 3], zbuf[5 * i + 4] if sets[i][7] is not None else None) for i in range(2)])
         # one fold per weight for BOTH sets' partial slots (fixed order): (2, P, K, M) -> (2, K, M) / (2, M, K)

@@ -74,6 +74,11 @@ def causal_conv1d_silu(x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
     return F.silu(out)
 
 
+# test hook: a list here receives (prefix, xc (b, E, L), dbc (b, L, R + 2N)) of every mamba_forward call, dbc with retain_grad() -- the
+# operands of the x_proj weight gradient, for the tests that localise an error to an operand (tests/test_configs.py)
+TRACE: Optional[list] = None
+
+
 def mamba_forward(sd: Dict[str, Tensor], pfx: str, hidden: Tensor) -> Tensor:
     """One `Mamba.forward` (slow-path math of mamba-ssm 1.2.0 `mamba_inner_fn`).  hidden: (b, L, D)."""
     w_in = sd[pfx + "in_proj.weight"]
@@ -86,6 +91,9 @@ def mamba_forward(sd: Dict[str, Tensor], pfx: str, hidden: Tensor) -> Tensor:
     x, z = xz[:, :E], xz[:, E:]
     xc = causal_conv1d_silu(x, sd[pfx + "conv1d.weight"].squeeze(1), sd.get(pfx + "conv1d.bias"))
     dbc = F.linear(xc.transpose(1, 2), sd[pfx + "x_proj.weight"])  # (b, L, R+2N)
+    if TRACE is not None:
+        dbc.retain_grad()
+        TRACE.append((pfx, xc.detach(), dbc))
     dt_lr, Bm, Cm = torch.split(dbc, [R, N, N], dim=-1)
     delta = (w_dt @ dt_lr.transpose(1, 2))  # (b, E, L)
     y = selective_scan(xc, delta, A, Bm.transpose(1, 2), Cm.transpose(1, 2), sd[pfx + "D"].float(), z,

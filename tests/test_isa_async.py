@@ -188,3 +188,138 @@ def test_legacy_multiply_is_compiler_visible(tmp_path):
         if t and not t.startswith((";", ".")):
             prev = t
     assert n >= 8, n  # one per item of a lane's segment in the gate gradient
+
+
+# ---- general lint: inline asm and the producer -> consumer wait states the compiler only pads for instructions it can SEE ------------------
+# gfx940-class hardware does not interlock (i) a transcendental's result read by the next VALU instruction (1 wait state), (ii) a matrix
+# core (MFMA) result read by a VALU instruction (passes + 3 wait states: 11 for the 8-pass 16x16x32 forms), (iii) a DOT result read by a
+# non-DOT VALU instruction.  LLVM's hazard recognizer inserts the s_nop -- for MachineInstrs.  An inline-asm block is ONE opaque
+# instruction to it: it knows the registers the block reads and writes, not that the block holds a VALU / transcendental / MFMA.  So the
+# two unprotected shapes are: a producer of class (i)-(iii) directly in front of an inline-asm VALU instruction that reads its result
+# (round 5: v_mul_legacy_f32 behind v_rcp_f32, found on the device only), and a producer of those classes INSIDE an asm block directly in
+# front of any reader.  Checked on the gfx950 assembly of every kernel of the library, in layout order inside a basic block.
+_TRANS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rcp_iflag_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32",
+          "v_exp_f16", "v_log_f16", "v_rcp_f16", "v_rsq_f16", "v_sqrt_f16")
+_NEED = {"trans": 1, "mfma": 11, "dot": 3}
+
+
+def _klass(op):
+    if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+        return "mfma"
+    if op.startswith("v_dot"):
+        return "dot"
+    if op.split("_e32")[0].split("_e64")[0].split("_dpp")[0].split("_sdwa")[0] in _TRANS:
+        return "trans"
+    return None
+
+
+def _reg_set(tok):
+    tok = tok.strip().rstrip(",")
+    m = re.match(r"[va]\[(\d+):(\d+)\]", tok)
+    if m:
+        return {(tok[0], r) for r in range(int(m.group(1)), int(m.group(2)) + 1)}
+    m = re.match(r"[va](\d+)$", tok)
+    return {(tok[0], int(m.group(1)))} if m else set()
+
+
+def _split_operands(text):
+    ops = [o for o in re.split(r",\s*|\s+", text.strip()) if o]
+    return ops
+
+
+def lint_asm_hazards(body):
+    """Returns the list of violations in one kernel body (assembly text)."""
+    bad = []
+    hist = []  # recent instructions of the current basic block: (op, dest regs, in_asm, wait states it provides)
+    in_asm = False
+    for raw in body.split("\n"):
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";"):
+            continue
+        if t.endswith(":") or t.startswith("."):
+            if re.match(r"^\.?L?BB\d+_\d+:", t) or t.endswith(":"):
+                hist = []  # a label: the predecessor is unknown, nothing can be concluded (and nothing is assumed)
+            continue
+        t = t.split(";")[0].strip()
+        parts = t.split(None, 1)
+        op, rest = parts[0], (parts[1] if len(parts) > 1 else "")
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+            hist = []
+            continue
+        ops = _split_operands(rest)
+        dest = _reg_set(ops[0]) if ops and op.startswith("v_") else set()
+        srcs = set()
+        if op.startswith("v_"):
+            for o in ops[1:]:
+                srcs |= _reg_set(o)
+            if op.startswith(("v_mfma", "v_smfmac", "v_fmac", "v_pk_fma", "v_dot")) and ops:
+                srcs |= set()  # (the accumulator is among ops[1:] already)
+            if op.startswith(("v_fmac", "v_mac", "v_dot2c", "v_dot4c", "v_dot8c")):
+                srcs |= dest  # reads its destination
+        if op.startswith("v_") and srcs:
+            slots = 0
+            for pop, pdest, pasm, pws in reversed(hist):
+                k = _klass(pop)
+                if k and (in_asm or pasm) and (pdest & srcs):
+                    same = (k == "mfma" and _klass(op) == "mfma") or (k == "dot" and _klass(op) == "dot")  # back-to-back accumulation is interlocked
+                    if not same and slots < _NEED[k]:
+                        bad.append(f"`{t}` reads the result of `{pop}` after {slots} wait state(s) (needs {_NEED[k]}); "
+                                   f"{'consumer' if in_asm else 'producer'} is inline asm")
+                slots += pws
+                if slots >= 12:
+                    break
+        ws = 1
+        if op == "s_nop":
+            ws = int(ops[0]) + 1 if ops else 1
+        hist.append((op, dest, in_asm, ws))
+        if len(hist) > 16:
+            hist.pop(0)
+    return bad
+
+
+def test_asm_hazard_lint_catches_the_round5_bug():
+    """The lint on the failing shape of round 5 and on its fixed forms."""
+    bug = "\n".join(["v_rcp_f32_e32 v5, v4", ";;#ASMSTART", "v_mul_legacy_f32 v6, v7, v5", ";;#ASMEND"])
+    assert lint_asm_hazards(bug)
+    ok1 = "\n".join(["v_rcp_f32_e32 v5, v4", "s_nop 0", ";;#ASMSTART", "v_mul_legacy_f32 v6, v7, v5", ";;#ASMEND"])
+    ok2 = "\n".join(["v_rcp_f32_e32 v5, v4", "v_mul_legacy_f32_e32 v6, v7, v5"])  # compiler-visible: padded by the hazard recognizer if needed
+    ok3 = "\n".join(["v_rcp_f32_e32 v5, v4", ";;#ASMSTART", "v_mul_legacy_f32 v6, v7, v8", ";;#ASMEND"])
+    assert not lint_asm_hazards(ok1) and not lint_asm_hazards(ok2) and not lint_asm_hazards(ok3)
+    mf = "\n".join(["v_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]", "s_nop 4", ";;#ASMSTART",
+                    "v_cvt_pk_bf16_f32 v12, v0, v1", ";;#ASMEND"])
+    assert lint_asm_hazards(mf)  # 6 wait states < 11
+    asm_prod = "\n".join([";;#ASMSTART", "v_exp_f32 v5, v4", ";;#ASMEND", "v_add_f32_e32 v6, v5, v5"])
+    assert lint_asm_hazards(asm_prod)
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_asm_hazard_lint_every_kernel(tmp_path):
+    """Every kernel of the library (all csrc/*.hip, every instantiation), gfx950 assembly."""
+    import glob
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = sorted(glob.glob(os.path.join(ROOT, "caduceus_amd", "csrc", "*.hip")))
+
+    def compile_one(src):
+        out = tmp_path / (os.path.basename(src) + ".s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Wno-pass-failed", "-S",
+                               "--cuda-device-only", "-o", str(out), src], stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+    with ThreadPoolExecutor(4) as ex:
+        asms = list(ex.map(compile_one, srcs))
+    n_kernels = n_asm = 0
+    problems = []
+    for src, asm in zip(srcs, asms):
+        for name, body in _kernel_bodies(asm).items():
+            n_kernels += 1
+            n_asm += body.count(";;#ASMSTART")
+            for v in lint_asm_hazards(body):
+                problems.append(f"{os.path.basename(src)} {name[:70]}: {v}")
+    assert n_kernels >= 40 and n_asm >= 100, (n_kernels, n_asm)  # the scan kernels alone hold hundreds of asm statements
+    assert not problems, "\n".join(problems[:20])
