@@ -188,7 +188,7 @@ VALU_PRICE_NS = {"valu": 1.15, "valu_mov": 1.0, "valu_sel": 1.0, "valu_lane": 1.
                  "trans": 3.4}
 # static instruction mix of the production scan kernels (tools/make_scan_isa_json.py), quoted like the counter profile: only for the
 # scan sources it was counted on
-SCAN_ISA_FILE = os.path.join("profiles", "r05_scan_isa.json")
+SCAN_ISA_FILE = os.path.join("profiles", "r06_scan_isa.json")
 
 
 def valu_roofline(kind: str, pmc: dict, isa: dict, avg_ms: float, n_simds: int):
@@ -218,7 +218,7 @@ def valu_roofline(kind: str, pmc: dict, isa: dict, avg_ms: float, n_simds: int):
 
 # counter profile of the two scan kernels at the headline launch shape (tools/prof_scan.sh + tools/make_scan_pmc_json.py), stamped with
 # the library and scan-source hashes it was taken on; quoted in `roofline` only while pmc_quotable() holds
-SCAN_PMC_FILE = os.path.join("profiles", "r05_scan_pmc.json")
+SCAN_PMC_FILE = os.path.join("profiles", "r06_scan_pmc.json")
 
 
 def pmc_quotable(pmc: dict, lib_version: str):
@@ -518,8 +518,17 @@ def main():
             xx = torch.randn(Tt, args.d_model, device=dev, dtype=amp)
             ww = torch.randn(2 * E, args.d_model, device=dev, dtype=amp)
             from caduceus_amd import ops as _ops
-            own = _ops.proj_supported(xx, args.d_model)  # the product path of the mixer (csrc/gemm.hip), else hipBLASLt
+            # the kernel the product path DISPATCHES for the in_proj of this width (mixer.BiMambaMixerFn.forward): d_model > 256 ->
+            # cad_gemm_stream with both operands streamed (B = W_in^T from the step cache), else the W-stationary cad_proj_wxT
+            from caduceus_amd import mixer as _mixer
+            own = _ops.proj_supported(xx, args.d_model)  # (csrc/gemm.hip), else hipBLASLt
+            kname = "cad_proj_wxT, own bf16 MFMA kernel" if own else "hipBLASLt"
             run = (lambda: _ops.proj_wxT(ww, xx)) if own else (lambda: torch.mm(ww, xx.t()))
+            if _mixer._STREAM_PROJ_D512 and args.d_model > 256 and amp == torch.bfloat16:
+                wwT = ww.t().contiguous()
+                if _ops.gemm_out_t(xx, wwT) is not None:
+                    run = lambda: _ops.gemm_out_t(xx, wwT)  # noqa: E731
+                    kname = "cad_gemm_stream (CAD_GEMM_OUT_T_BF16, col_fastest), own bf16 MFMA kernel, both operands streamed"
             for _ in range(3):
                 run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -531,11 +540,11 @@ def main():
             ms = e0.elapsed_time(e1) / 10
             fl = 2.0 * Tt * args.d_model * 2 * E
             by = (Tt * args.d_model + 2 * E * args.d_model + Tt * 2 * E) * (2 if args.dtype == "bf16" else 4)
-            proj = {"kernel": "in_proj GEMM (" + ("cad_proj_wxT, own bf16 MFMA kernel" if own else "hipBLASLt") + ")", "ms": ms,
+            proj = {"kernel": "in_proj GEMM (" + kname + ")", "ms": ms,
                     "TFLOPs": fl / ms / 1e9, "mfma_peak_TFLOPs": 2500.0 if args.dtype == "bf16" else 157.3,
                     "GBps": by / ms / 1e6, "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS,
                     "note": "K = d_model: HBM-bound (arithmetic intensity ~200 flop/B), not MFMA-bound; per-kernel MFMA-busy and "
-                            "fabric-byte counters of the whole step in profiles/r04_step_pmc_summary.txt"}
+                            "fabric-byte counters of the whole step in profiles/r06_step_pmc_summary.txt"}
             if args.fp8_proj and _ops.fp8_proj_supported(xx, args.d_model):
                 wq, sw = _ops.quant_weight_fp8(ww)
                 xq, sx = _ops.quant_rows_fp8(xx)

@@ -66,6 +66,10 @@ class GemmStreamArgs(C.Structure):
                 ("nslices", _i), ("mode", _i), ("col_fastest", _i)]
 
 
+class FoldF32Job(C.Structure):
+    _fields_ = [("src", _p), ("dst", _p), ("n", _i64), ("stride", _i64), ("stride2", _i64), ("nparts", _i), ("nparts2", _i)]
+
+
 class Conv1dBwdArgs(C.Structure):
     _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("dout", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
                 ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i),
@@ -151,6 +155,8 @@ SYMBOLS = {
     "cad_fold_partials_stream": (_i, [C.POINTER(FoldArgs), _i, _i, _p]),
     "cad_fold_stream_supported": (_i, [_i, _i, _i64, _i]),
     "cad_scan_bwd_chunk_len": (_i64, []),
+    "cad_scan_bwd_fold_counter_ints": (_i64, [_i64, _i64]),
+    "cad_stream_probe": (_i, [_p, _p, _p, _p, _i64]),
     "cad_scan_bwd_gate_fix": (_i, [C.POINTER(ScanBwdArgs), _i, _p]),
     "cad_scan_gate_fix_entries": (_i64, [_i, _i64, _i64]),
     "cad_proj_wxT": (_i, [C.POINTER(ProjArgs), _p]),
@@ -166,6 +172,7 @@ SYMBOLS = {
     "cad_proj_xTw_supported": (_i, [_i, _i, _i64]),
     "cad_gemm_stream": (_i, [C.POINTER(GemmStreamArgs), _p]),
     "cad_gemm_stream_supported": (_i, [_i64, _i64, _i64, _i]),
+    "cad_fold_f32_multi": (_i, [C.POINTER(FoldF32Job), _i, _p]),
     "cad_quant_rows_fp8": (_i, [C.POINTER(QuantFp8Args), _p]),
     "cad_proj_wxT_fp8": (_i, [C.POINTER(ProjFp8Args), _p]),
     "cad_proj_fp8_supported": (_i, [_i]),

@@ -191,11 +191,20 @@ __device__ __forceinline__ void cad_counter_add_agent(int* p, int v) {
 __device__ __forceinline__ int cad_counter_load_agent(const int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// which CU this wave runs on, as a small table index: XCC_ID (0..15) x the {se_id, sh_id, cu_id} field of HW_REG_HW_ID (bits 15:8)
+#define CAD_CU_KEYS 4096
+__device__ __forceinline__ int cad_cu_key() {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return (int)(((xcc & 15u) << 8) | ((hw >> 8) & 255u));
+}
 #ifndef CAD_POLL_SLEEP
 #define CAD_POLL_SLEEP 32
 #endif
 __device__ __forceinline__ void cad_poll_sleep() { __builtin_amdgcn_s_sleep(CAD_POLL_SLEEP); }  // 64 cycles per unit
 __device__ __forceinline__ uint64_t cad_wall_clock() { return wall_clock64(); }             // constant-rate counter
+#define CAD_WALL_CLOCK_TICKS_PER_US 100ull  /* the wall clock of the device side runs at 100 MHz */
 __device__ __forceinline__ uint64_t cad_wall_clock_hz() { return 100000000ull; }            // 100 MHz on gfx9 (s_memrealtime)
 
 // more than 64 KB of dynamic LDS has to be requested per kernel: the largest size asked for so far is remembered per call site (= per

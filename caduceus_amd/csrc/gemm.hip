@@ -1201,3 +1201,59 @@ extern "C" int cad_gemm_stream(const cad_gemm_stream_args* a, void* stream) {
     }
     return cad_after_launch();
 }
+
+// ---- cad_fold_f32_multi: the fp32 partial tiles of a layer's weight gradients, every sum in one launch --------------------------------
+namespace {
+struct FoldF32Jobs {
+    cad_fold_f32_job j[CAD_FOLD_F32_MAX_JOBS];
+    int first_block[CAD_FOLD_F32_MAX_JOBS + 1];  // blocks [first_block[i], first_block[i + 1]) work on job i
+    int njobs;
+};
+#define FF_THREADS 256
+__global__ __launch_bounds__(FF_THREADS) void fold_f32_multi_kernel(FoldF32Jobs jobs) {
+    int ji = 0;
+    while (ji + 1 < jobs.njobs && (int)blockIdx.x >= jobs.first_block[ji + 1]) ++ji;  // (wave-uniform: blockIdx)
+    const cad_fold_f32_job& jb = jobs.j[ji];
+    const int64_t i = ((int64_t)((int)blockIdx.x - jobs.first_block[ji]) * FF_THREADS + threadIdx.x) * 4;
+    if (i >= jb.n) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j2 = 0; j2 < jb.nparts2; ++j2) {
+        const float* p = jb.src + (int64_t)j2 * jb.stride2 + i;
+        int k = 0;
+        for (; k + 4 <= jb.nparts; k += 4) {  // four loads in flight, added in order
+            const f32x4 a = *(const f32x4*)(p + (int64_t)k * jb.stride);
+            const f32x4 b = *(const f32x4*)(p + (int64_t)(k + 1) * jb.stride);
+            const f32x4 c = *(const f32x4*)(p + (int64_t)(k + 2) * jb.stride);
+            const f32x4 d = *(const f32x4*)(p + (int64_t)(k + 3) * jb.stride);
+            acc = acc + a;
+            acc = acc + b;
+            acc = acc + c;
+            acc = acc + d;
+        }
+        for (; k < jb.nparts; ++k) acc = acc + *(const f32x4*)(p + (int64_t)k * jb.stride);
+    }
+    *(f32x4*)(jb.dst + i) = acc;
+}
+}  // namespace
+
+extern "C" int cad_fold_f32_multi(const cad_fold_f32_job* jobs, int njobs, void* stream) {
+    CAD_CHECK_ARG(jobs && njobs >= 1 && njobs <= CAD_FOLD_F32_MAX_JOBS);
+    FoldF32Jobs kj;
+    kj.njobs = njobs;
+    int64_t blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const cad_fold_f32_job& j = jobs[i];
+        CAD_CHECK_ARG(j.src && j.dst && j.n > 0 && j.n % 4 == 0 && j.nparts >= 1 && j.nparts2 >= 1);
+        CAD_CHECK_ARG(j.stride % 4 == 0 && j.stride2 % 4 == 0 && (((uintptr_t)j.src | (uintptr_t)j.dst) % 16) == 0);
+        kj.j[i] = j;
+        kj.first_block[i] = (int)blocks;
+        blocks += (j.n / 4 + FF_THREADS - 1) / FF_THREADS;
+        CAD_CHECK_ARG(blocks < (1 << 30));
+    }
+    for (int i = njobs; i < CAD_FOLD_F32_MAX_JOBS; ++i) kj.j[i] = jobs[0], kj.first_block[i] = (int)blocks;
+    kj.first_block[njobs] = (int)blocks;
+    for (int i = njobs + 1; i <= CAD_FOLD_F32_MAX_JOBS; ++i) kj.first_block[i] = (int)blocks;
+    dim3 grid((unsigned)blocks), block(FF_THREADS);
+    CAD_LAUNCH(fold_f32_multi_kernel, grid, block, 0, stream, kj);
+    return cad_after_launch();
+}

@@ -187,6 +187,15 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     // concurrent fold (cad_fold_partials_stream on another stream, include/caduceus_hip.h): one arrival per (row, chunk) and workgroup,
     // published once every slot store of the chunk has left the CU
     int* pub = (!CO && a.fold_counters) ? a.fold_counters + sb * nchunks : nullptr;
+    // ... and one "this workgroup is resident" arrival (the int behind the SB x nchunks chunk counters): cad_fold_partials_stream's
+    // gate launch lets the fold kernel onto the CUs only once the scan's workgroups are placed (see fold_gate_kernel)
+    // ... and marks the CU it runs on (CAD_CU_KEYS ints behind that): a fold workgroup that finds no scan workgroup on its CU while scan
+    // workgroups are still waiting for a CU (another kernel -- an RCCL all-reduce -- held theirs when the launch started) leaves at once
+    // instead of blocking that CU for the whole scan
+    if (pub && threadIdx.x == 0) {
+        cad_counter_add_agent(a.fold_counters + SB * nchunks, 1);
+        cad_counter_add_agent(a.fold_counters + SB * nchunks + 1 + cad_cu_key(), 1);
+    }
 
     StageRegs<T, SC_SV(SC_S)> st;
     StageCtx<T> sctx = sc_stage_ctx<T, SC_S>(Bm, Cm, SB, sb, L);
@@ -973,6 +982,33 @@ __global__ void reduce_partials_multi_kernel(ReduceJobs jobs, int nparts, int64_
 struct FoldSets {
     cad_fold_args s[SC_MAXSETS];
 };
+// Placement gate.  The fold kernel must reach a CU AFTER the scan workgroup it shares that CU with: a 48-VGPR / 10 KB allocation that
+// lands first -- or next to the waves of a third kernel that then leave (the carry pass of an L-split backward, an RCCL all-reduce) --
+// sits in the MIDDLE of the register file / LDS and leaves no contiguous 2 x 232 VGPRs / 132 KB for the scan workgroup: measured, the
+// full pass of an L-split backward did not start until the fold gave up 20 ms later (profiles/r06_ab_stream_fold.txt).  So one wave runs
+// AHEAD of the fold kernel on its stream and returns only when the scan's workgroups have been placed: every scan workgroup adds 1 to
+// counters[SB x nchunks] as it starts; the gate waits for the first arrival, then until the count has stopped rising for ~20 us (a whole
+// grid is dispatched within a microsecond; a launch with more workgroups than CUs stalls at the resident ones) or the budget is spent.
+__global__ __launch_bounds__(64) void fold_gate_kernel(FoldSets sets, int nsets, int want, uint64_t budget_ticks) {
+    if (threadIdx.x != 0) return;
+    const uint64_t t0 = cad_wall_clock();
+    int last = -1;
+    uint64_t t_change = t0;
+    for (;;) {
+        int n = 0;
+        for (int i = 0; i < nsets; ++i) {
+            const cad_fold_args& a = sets.s[i];
+            n += cad_counter_load_agent(a.counters + a.SB * (a.L / FOLD_CHUNK));
+        }
+        const uint64_t now = cad_wall_clock();
+        if (n >= want) return;
+        if (n != last) last = n, t_change = now;
+        if (n > 0 && now - t_change >= 2000) return;   // 20 us without a new workgroup: everything that fits is resident
+        if (now - t0 >= budget_ticks) return;          // the scan is not running next to us: the fold kernel deals with that itself
+        cad_poll_sleep();
+    }
+}
+
 #define FOLD_MAX_ITEMS 256  // items (slice, row, set) one workgroup may be given
 #ifndef FOLD_WAKE_DIV
 #define FOLD_WAKE_DIV 4
@@ -1004,6 +1040,29 @@ __global__ __launch_bounds__(FOLD_T) void fold_stream_kernel(FoldSets sets, int 
         const cad_fold_args& a = sets.s[item_set(j)];
         return a.abort_from ? a.abort_from + (int64_t)item_row(j) * G + item_slice(j) : nullptr;
     };
+    if (mode == CAD_FOLD_CONCURRENT) {
+        // co-location check (see scan_bwd_kernel): not next to a scan workgroup AND scan workgroups still unplaced -> this workgroup is
+        // in their way (its registers / LDS sit where theirs must go): hand everything to the cleanup launch and leave
+        if (t == 0) {
+            int started = 0, here = 0;
+            const int key = cad_cu_key();
+            for (int i = 0; i < nsets; ++i) {
+                const int* base = sets.s[i].counters + sets.s[i].SB * nchunks;
+                started += cad_counter_load_agent(base);
+                here += cad_counter_load_agent(base + 1 + key);
+            }
+            pick_s[0] = (here == 0 && started < total) ? 1 : 0;
+        }
+        __syncthreads();
+        if (pick_s[0]) {
+            for (int j = t; j < nitems; j += FOLD_T) {
+                int* as = abort_slot(j);
+                if (as) *as = (int)nchunks;
+            }
+            return;
+        }
+        __syncthreads();  // pick_s is rewritten below
+    }
     for (int j = t; j < nitems; j += FOLD_T) {
         int c = (int)nchunks - 1;
         if (mode == CAD_FOLD_CLEANUP) {  // what a concurrent pass left (stored as chunk + 1: 0 = nothing)
@@ -1249,7 +1308,34 @@ extern "C" int cad_scan_bwd_gate_fix(const cad_scan_bwd_args* sets, int nsets, v
     return cad_after_launch();
 }
 
+namespace {
+__global__ __launch_bounds__(64) void stream_probe_wait_kernel(const int* flag, int* result, uint64_t budget_ticks) {
+    if (threadIdx.x != 0) return;
+    const uint64_t t0 = cad_wall_clock();
+    int seen = 0;
+    do {
+        seen = cad_counter_load_agent(flag) != 0;
+        if (!seen) cad_poll_sleep();
+    } while (!seen && cad_wall_clock() - t0 < budget_ticks);
+    result[0] = seen;
+}
+__global__ __launch_bounds__(64) void stream_probe_set_kernel(int* flag) {
+    if (threadIdx.x == 0) cad_counter_add_agent(flag, 1);
+}
+}  // namespace
+
+extern "C" int cad_stream_probe(void* stream_a, void* stream_b, int* flag, int* result, int64_t budget_us) {
+    CAD_CHECK_ARG(flag && result && budget_us > 0 && budget_us <= 1000000);
+    CAD_LAUNCH(stream_probe_wait_kernel, dim3(1), dim3(64), 0, stream_a, (const int*)flag, result,
+               (uint64_t)budget_us * CAD_WALL_CLOCK_TICKS_PER_US);
+    CAD_LAUNCH(stream_probe_set_kernel, dim3(1), dim3(64), 0, stream_b, flag);
+    return cad_after_launch();
+}
+
 extern "C" int64_t cad_scan_bwd_chunk_len(void) { return SC_CHUNK; }
+extern "C" int64_t cad_scan_bwd_fold_counter_ints(int64_t SB, int64_t L) {
+    return SB * ((L + SC_CHUNK - 1) / SC_CHUNK) + 1 + CAD_CU_KEYS;
+}
 
 extern "C" int cad_fold_stream_supported(int N, int n_partials, int64_t L, int dtype) {
     if (dtype != CAD_BF16 || N < 1 || L < FOLD_CHUNK || L % FOLD_CHUNK != 0 || SC_CHUNK != FOLD_CHUNK) return 0;
@@ -1290,6 +1376,8 @@ extern "C" int cad_fold_partials_stream(const cad_fold_args* sets, int nsets, in
     const int cus = cad_cu_count();  // one workgroup per CU at most (see the kernel)
     if (items > (int64_t)cus * FOLD_MAX_ITEMS) return CAD_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(items < cus ? items : cus)), block(FOLD_T);
+    if (mode == CAD_FOLD_CONCURRENT)  // (same stream: the fold kernel is dispatched when the gate has returned)
+        CAD_LAUNCH(fold_gate_kernel, dim3(1), dim3(64), 0, stream, ks, nsets, (int)items, budget);
     CAD_LAUNCH(fold_stream_kernel, grid, block, 0, stream, ks, nsets, mode, budget);
     return cad_after_launch();
 }

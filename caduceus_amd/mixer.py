@@ -161,6 +161,11 @@ _FP8_IN_PROJ = os.environ.get("CADUCEUS_AMD_FP8_PROJ", "0") == "1"
 # issue, the fold by memory latency: 0.39 ms per layer of fold kernel leave the critical path); CADUCEUS_AMD_STREAM_FOLD=0: the fold
 # kernel behind the scan (cad_reduce_partials_multi) -- same summation order, bit-identical gradients
 _STREAM_FOLD = os.environ.get("CADUCEUS_AMD_STREAM_FOLD", "1") != "0"
+_STREAM_FOLD_MIN_CHUNKS = 16  # rows shorter than this many 512-position chunks keep the fold kernel behind the scan (see backward)
+# the fp32 partial tiles of a layer's weight gradients (dW_in, dW_out: K slices of cad_gemm_stream; dW_x, dW_dt: per-workgroup slots of
+# cad_proj_wx_wgrad) summed by ONE own launch at the end of the backward (cad_fold_f32_multi) instead of four torch reductions + an add;
+# CADUCEUS_AMD_GLUE_FOLD=0: torch.sum per tensor
+_GLUE_FOLD = os.environ.get("CADUCEUS_AMD_GLUE_FOLD", "1") != "0"
 
 
 # test hook (tests/test_configs.py): a list here receives, per backward call, the operands of the x_proj weight gradient of both
@@ -392,8 +397,18 @@ class BiMambaMixerFn(torch.autograd.Function):
             dy = torch.mm(w_out.t(), dout2d.t())
         dy = dy.view(E, SB, Lq)
         y_f, y_r = ycat[:E], ycat[E:]
-        dW_cat = _wgrad_cm_tm(ycat.view(2 * E, T), dout2d)  # (2E, D): both halves multiply the same tied weight
-        dW_out = (dW_cat[:E] + dW_cat[E:]).t()
+        glue = []  # (src, dst, n, nparts, stride, nparts2, stride2) jobs of the one fp32 fold launch at the end (_GLUE_FOLD)
+        part_out = None
+        if _GLUE_FOLD and _OWN_GEMM and (Dm <= 256 or _OWN_GEMM_D512):
+            part_out = ops.wgrad_cm_tm(ycat.view(2 * E, T), dout2d, return_partials=True)  # (slices, 2E, D)
+        if part_out is not None:
+            # both halves multiply the same tied weight: the fold adds them (second level) as it sums the slices
+            dW_out_ED = torch.empty((E, Dm), dtype=torch.float32, device=x2d.device)
+            glue.append((part_out, dW_out_ED, E * Dm, part_out.shape[0], 2 * E * Dm, 2, E * Dm))
+            dW_out = dW_out_ED.t()
+        else:
+            dW_cat = _wgrad_cm_tm(ycat.view(2 * E, T), dout2d)  # (2E, D): both halves multiply the same tied weight
+            dW_out = (dW_cat[:E] + dW_cat[E:]).t()
         dxz = torch.empty_like(xz)       # [dx ; dz]: the gate z is shared, set 0's kernel writes the gradient of both gates
         sets = [rest[12 * i:12 * i + 12] for i in range(2)]
         args = (L.ScanBwdArgs * 2)()
@@ -405,10 +420,16 @@ class BiMambaMixerFn(torch.autograd.Function):
         zshapes += [(1,), (1,)]  # worklist counters of the exact z == 0 gate gradient (int32 views of zero bits)
         N0 = sets[0][2].shape[1]
         npart0 = lib.cad_scan_bwd_partials(E)
-        stream_fold = (_STREAM_FOLD and sets[1][2].shape[1] == N0 and ops.fold_stream_supported(N0, npart0, Lq // k, act))
+        nch = max(1, (Lq // k) // int(lib.cad_scan_bwd_chunk_len()))
+        # (the fold follows the scan chunk by chunk with one workgroup per CU: it pays for long rows -- many chunks per (row, slice) item,
+        # few items per workgroup; short rows in large batches (configs[1]: 2 chunks, 64 items per workgroup) keep the streaming fold
+        # kernel behind the scan: 4.18 vs 4.83 ms per layer, profiles/r06_ab_stream_fold.txt)
+        stream_fold = (_STREAM_FOLD and sets[1][2].shape[1] == N0 and ops.fold_stream_supported(N0, npart0, Lq // k, act)
+                       and nch >= _STREAM_FOLD_MIN_CHUNKS and npart0 * SB * k * 2 <= 4 * ops._cu_count()
+                       and ops.fold_side_available(x2d.device))
         if stream_fold:  # arrival counters (set, row, chunk) and give-up records (set, row, slice) of the concurrent fold: zero bits
-            nch = (Lq // k) // int(lib.cad_scan_bwd_chunk_len())
-            zshapes += [(2, SB * k, nch), (2, SB * k, npart0)]
+            nci = (int(lib.cad_scan_bwd_fold_counter_ints(SB * k, Lq // k)) + 3) // 4 * 4  # chunk arrivals + started count + CU marks
+            zshapes += [(2, nci), (2, SB * k, npart0)]
         zbuf = _zeros_f32(zshapes, x2d.device)
         fix_cnt = [zbuf[10].view(torch.int32), zbuf[11].view(torch.int32)]
         n_fix = lib.cad_scan_gate_fix_entries(E, SB, Lq)
@@ -512,10 +533,44 @@ class BiMambaMixerFn(torch.autograd.Function):
         conv_g = _conv_bwd2(x, [(sets[i][6], sets[i][7]) for i in range(2)], dxcs, dxz[:E], split, dirs,
                             bufs=[(zbuf[5 * i + 3], zbuf[5 * i + 4] if sets[i][7] is not None else None) for i in range(2)])
         # one fold per weight for BOTH sets' partial slots (fixed order): (2, P, K, M) -> (2, K, M) / (2, M, K)
-        sum_dt = None if wg_dt is None else wg_dt.sum(dim=1)
         # (the slots hold (K, M); summed as they lie -- a reduction over a permuted view runs at a quarter of the rate -- and the
         # small (2, K, M) result is transposed)
-        sum_x = None if wg_x is None else wg_x.sum(dim=1).transpose(1, 2).contiguous()
+        sum_dt = sum_x_km = None
+        if _GLUE_FOLD:
+            for wg, name in ((wg_dt, "dt"), (wg_x, "x")):
+                if wg is not None:
+                    _, P_, K_, M_ = wg.shape
+                    res = torch.empty((2, K_, M_), dtype=torch.float32, device=x2d.device)
+                    for i in range(2):
+                        glue.append((wg[i], res[i], K_ * M_, P_, K_ * M_, 1, 0))
+                    if name == "dt":
+                        sum_dt = res
+                    else:
+                        sum_x_km = res
+        else:
+            sum_dt = None if wg_dt is None else wg_dt.sum(dim=1)
+            sum_x_km = None if wg_x is None else wg_x.sum(dim=1)
+        if dz_r is not None:
+            dxz[E:].add_(dz_r)
+        # d(x2d) and dW_in first (the fold launch below reads dW_in's partial tiles)
+        # (d_model 256: one 256-row tile, dxz read once; d_model 512: profiles/r05_gemm_stream_d512.txt)
+        dx2d = None
+        if _OWN_GEMM and (Dm <= 256 or _OWN_GEMM_D512):
+            w_inT = wT["in"] if (wT and wT.get("in") is not None) else w_in.t().contiguous()
+            dx2d = ops.proj_xTw_stream(w_inT, dxz.view(2 * E, T))
+        if dx2d is None:
+            dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
+        part_in = None
+        if _GLUE_FOLD and _OWN_GEMM and (Dm <= 256 or _OWN_GEMM_D512):
+            part_in = ops.wgrad_cm_tm(dxz.view(2 * E, T), x2d, return_partials=True)
+        if part_in is not None:
+            dW_in = torch.empty((2 * E, Dm), dtype=torch.float32, device=x2d.device)
+            glue.append((part_in, dW_in, 2 * E * Dm, part_in.shape[0], 2 * E * Dm, 1, 0))
+        else:
+            dW_in = None
+        if glue:
+            ops.fold_f32(glue)
+        sum_x = None if sum_x_km is None else sum_x_km.transpose(1, 2).contiguous()
         for i in range(2):
             meta = pmeta[i]
             (dwc, dbc_conv), (dW_x, dW_dt, dbias, dA_log, dD) = conv_g[i], part[i]
@@ -524,17 +579,8 @@ class BiMambaMixerFn(torch.autograd.Function):
             grads += [dwc.reshape(meta[0][1]).to(meta[0][0]), None if dbc_conv is None else dbc_conv.to(meta[1][0]),
                       dW_x.to(meta[2][0]), dW_dt.to(meta[3][0]), dbias.to(meta[4][0]), dA_log.to(meta[5][0]),
                       dD.to(meta[6][0])]
-        if dz_r is not None:
-            dxz[E:].add_(dz_r)
-        # (d_model 256: one 256-row tile, dxz read once; the configs[4] step with all three products on the own kernel measured 570.7 ms
-        # against 555.9 ms with the library: d_model 512 stays there)
-        dx2d = None
-        if _OWN_GEMM and (Dm <= 256 or _OWN_GEMM_D512):
-            w_inT = wT["in"] if (wT and wT.get("in") is not None) else w_in.t().contiguous()
-            dx2d = ops.proj_xTw_stream(w_inT, dxz.view(2 * E, T))
-        if dx2d is None:
-            dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
-        dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
+        if dW_in is None:
+            dW_in = _wgrad_cm_tm(dxz.view(2 * E, T), x2d)
         return (dx2d, None, None, None, None, None, dW_in.to(win_dt), dW_out.to(wout_dt), *grads)
 
 

@@ -330,10 +330,34 @@ def fold_stream_supported(N: int, npart: int, Lq: int, dtype) -> bool:
 
 
 def _fold_side(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """(side stream, event, event) whose kernels really run NEXT TO the current stream's, or None.  HIP serves all streams from a few
+    hardware queues: a second stream that shares the current stream's queue runs its kernels behind it (measured under torchrun + RCCL:
+    the process group's stream shifted the assignment, the fold ran after every scan, +8 ms per step).  So candidates are probed once
+    per (device, current stream) with cad_stream_probe -- one wave waiting up to 2 ms on one stream for a flag set from the other --
+    and the first stream that overlaps is kept; with none, the caller keeps the fold kernel behind the scan."""
+    main = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), main.cuda_stream)
     if key not in _FOLD_SIDE:
-        _FOLD_SIDE[key] = (torch.cuda.Stream(device), torch.cuda.Event(), torch.cuda.Event())
+        lib = L.get_lib()
+        found = None
+        buf = torch.zeros((16, 2), dtype=torch.int32, device=device)
+        for i in range(8):
+            cand = torch.cuda.Stream(device)
+            cand.wait_stream(main)  # (the zero fill above)
+            L.check(lib.cad_stream_probe(C.c_void_p(main.cuda_stream), C.c_void_p(cand.cuda_stream), L.ptr(buf[i, 0:1]),
+                                         L.ptr(buf[i, 1:2]), 2000), "cad_stream_probe")
+            main.wait_stream(cand)
+            if int(buf[i, 1].item()) == 1:  # (one host synchronisation per candidate, once per process)
+                found = cand
+                break
+        _FOLD_SIDE[key] = None if found is None else (found, torch.cuda.Event(), torch.cuda.Event())
+        if os.environ.get("CADUCEUS_AMD_VERBOSE"):
+            print(f"caduceus_amd: concurrent fold stream for {key}: {'candidate %d' % i if found is not None else 'none (fold kernel behind the scan)'}")
     return _FOLD_SIDE[key]
+
+
+def fold_side_available(device) -> bool:
+    return (not L.is_device_build()) or _fold_side(device) is not None
 
 
 FOLD_GIVE_UPS = None  # a list: every device launch appends the number of give-up records (a device scalar) of its concurrent pass
@@ -724,9 +748,24 @@ def gemm_stream_slices(R: int, Cc: int, K: int) -> int:
     return n if K % (32 * n) == 0 else 0
 
 
-def wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> Optional[torch.Tensor]:
+def fold_f32(jobs) -> None:
+    """cad_fold_f32_multi: jobs = [(src, dst, n, nparts, stride, nparts2, stride2)], src / dst fp32 tensors (src addressed from its data
+    pointer: dst[i] = sum_{j < nparts2, k < nparts} src[j * stride2 + k * stride + i]) -- every sum in ONE launch."""
+    arr = (L.FoldF32Job * len(jobs))()
+    tensors = []
+    for q, (src, dst, n, nparts, stride, nparts2, stride2) in enumerate(jobs):
+        if src.dtype != torch.float32 or dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() != n:
+            raise ValueError("fold_f32: fp32 tensors, dst contiguous with n elements")
+        arr[q] = L.FoldF32Job(L.ptr(src), L.ptr(dst), n, stride, stride2, nparts, nparts2)
+        tensors += [src, dst]
+    stream = L.stream_and_check(*tensors, contiguous=False)
+    L.check(L.get_lib().cad_fold_f32_multi(arr, len(jobs), stream), "cad_fold_f32_multi")
+
+
+def wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor, return_partials: bool = False) -> Optional[torch.Tensor]:
     """(M, N) fp32 = a (M, T) channel-major @ b (T, N) token-major, bf16 operands, fp32 accumulation over ALL tokens (cad_gemm_stream,
-    CAD_GEMM_PARTIALS: one fp32 tile per K slice, summed here): dW_in and dW_out of the mixer.  None if the shape is not served."""
+    CAD_GEMM_PARTIALS: one fp32 tile per K slice, summed here): dW_in and dW_out of the mixer.  None if the shape is not served.
+    return_partials: the (slices, M, N) partial tiles as they are (the caller folds them, e.g. with fold_f32 next to other sums)."""
     M, T = a_cm.shape
     N = b_tm.shape[1]
     if a_cm.dtype != torch.bfloat16 or b_tm.dtype != torch.bfloat16 or a_cm.stride(1) != 1 or b_tm.stride(1) != 1:
@@ -740,6 +779,8 @@ def wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> Optional[torch.Tensor
     stream = L.stream_and_check(a_cm, b_tm, part, contiguous=False)
     a = L.GemmStreamArgs(L.ptr(a_cm), L.ptr(b_tm), L.ptr(part), M, N, T, a_cm.stride(0), b_tm.stride(0), 0, n, GEMM_PARTIALS)
     L.check(L.get_lib().cad_gemm_stream(C.byref(a), stream), "cad_gemm_stream")
+    if return_partials:
+        return part
     return part[0] if n == 1 else part.sum(0)
 
 

@@ -268,7 +268,8 @@ typedef struct {
                         * (exp, C * dy, one chain per item and state); no other output is written, B / chunk_state / out are
                         * not read (du, ddelta, dA, dB, dC, dD, ddelta_bias, chunk_state may be NULL).  Pass 1 of an L-split
                         * backward (see map_only). */
-    int* fold_counters; /* optional (NULL = absent): (SB, ceil(L / cad_scan_bwd_chunk_len())) int32, zeroed by the caller.  When given, the
+    int* fold_counters; /* optional (NULL = absent): cad_scan_bwd_fold_counter_ints(SB, L) int32, zeroed by the caller (chunk arrivals
+                        * [row][chunk], ONE count of the workgroups that have started, one mark per CU hosting one).  When given, the
                         * dB / dC slot stores go out write-through and every workgroup adds 1 to counter [row][chunk] once ALL its
                         * slot stores of that 512-position chunk have left the CU, so that cad_fold_partials_stream -- launched on ANOTHER
                         * stream while this kernel runs -- can fold chunk by chunk behind it (a chunk is complete at
@@ -316,7 +317,7 @@ typedef struct {
     const void* dC_slots;
     void* dB;               /* (N, SB, L) */
     void* dC;
-    const int* counters;    /* the scan's fold_counters (CAD_FOLD_CONCURRENT) */
+    const int* counters;    /* the scan's fold_counters (CAD_FOLD_CONCURRENT): cad_scan_bwd_fold_counter_ints(SB, L) ints */
     int* abort_from;        /* (SB, n_partials) int32, zeroed by the caller: CAD_FOLD_CONCURRENT stores (chunk + 1) where a slice gave up,
                              * CAD_FOLD_CLEANUP folds chunks chunk .. 0 of such a slice and clears the entry; 0 = nothing left */
     int64_t SB, L, split;
@@ -327,6 +328,12 @@ typedef struct {
 int cad_fold_partials_stream(const cad_fold_args* sets, int nsets, int mode, void* stream);
 int cad_fold_stream_supported(int N, int n_partials, int64_t L, int dtype);
 int64_t cad_scan_bwd_chunk_len(void);
+/* Do kernels of `stream_b` run WHILE a kernel of `stream_a` runs?  HIP maps streams onto a few hardware queues; two streams on one queue
+ * are served in order, and a fold launched on such a stream simply runs after the scan (correct, but exposed and slower than the
+ * streaming fold kernel).  One wave on stream_a waits (bounded: budget_us) for a flag that one wave on stream_b sets; result[0] = 1 if it
+ * saw the flag, 0 if it ran out of time.  flag, result: device int32, zeroed by the caller; the caller synchronises and reads result. */
+int cad_stream_probe(void* stream_a, void* stream_b, int* flag, int* result, int64_t budget_us);
+int64_t cad_scan_bwd_fold_counter_ints(int64_t SB, int64_t L);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Dense projections of the mixer on the matrix cores (bf16 MFMA, fp32 accumulation).   Replace the `in_proj` /
@@ -431,6 +438,22 @@ typedef struct {
     int col_fastest;
 } cad_gemm_stream_args;
 int cad_gemm_stream(const cad_gemm_stream_args* a, void* stream);
+
+/* cad_fold_f32_multi: up to CAD_FOLD_F32_MAX_JOBS sums of fp32 partial tiles in ONE launch -- the per-workgroup / per-K-slice partials of the
+ * weight-gradient kernels of a mixer layer's backward (cad_gemm_stream's CAD_GEMM_PARTIALS slices, cad_proj_wx_wgrad's slots), which were
+ * one torch reduction each (the autograd glue around mamba_inner_fn's weight gradients, modeling_caduceus.py:11,128,130 has no such step:
+ * cuBLAS sums inside its GEMMs).  dst[i] = sum over j < nparts2, k < nparts of src[j * stride2 + k * stride + i], i < n, summed in that
+ * fixed order (k fastest): deterministic.  nparts2 = 1 for a plain fold; the second level adds, e.g., the two halves of the tied
+ * out_proj's weight gradient.  n % 4 == 0, strides % 4 == 0, src / dst 16-byte aligned. */
+#define CAD_FOLD_F32_MAX_JOBS 8
+typedef struct {
+    const float* src;
+    float* dst;
+    int64_t n;
+    int64_t stride, stride2;
+    int nparts, nparts2;
+} cad_fold_f32_job;
+int cad_fold_f32_multi(const cad_fold_f32_job* jobs, int njobs, void* stream);
 int cad_gemm_stream_supported(int64_t R, int64_t C, int64_t K, int nslices);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -184,11 +184,14 @@ __device__ __forceinline__ void cad_load16x4_wt(const void* const (&base)[4], ui
 }
 __device__ __forceinline__ void cad_counter_add_agent(int* p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 __device__ __forceinline__ int cad_counter_load_agent(const int* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+#define CAD_CU_KEYS 4096
+__device__ __forceinline__ int cad_cu_key() { return 0; }  // one "CU": every kernel of a test is co-located with every other
 __device__ __forceinline__ void cad_poll_sleep() {}
 __device__ __forceinline__ uint64_t cad_wall_clock() {
     static uint64_t t = 0;  // every call "takes" 1 ms: a poll that does not succeed runs out of its budget after a few calls
     return __atomic_add_fetch(&t, 100000, __ATOMIC_RELAXED);
 }
+#define CAD_WALL_CLOCK_TICKS_PER_US 100ull  /* the wall clock of the device side runs at 100 MHz */
 __device__ __forceinline__ uint64_t cad_wall_clock_hz() { return 100000000ull; }
 #define CAD_BIG_LDS(kern, bytes) (void)0
 

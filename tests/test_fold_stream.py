@@ -50,7 +50,10 @@ def test_fold_stream_bit_identical_to_reduce_partials(backend, G, N, SB, L, spli
     nch = L // CHUNK
     # (a) everything, no polling
     out = torch.full_like(want, float("nan"))
-    counters = torch.zeros((SB, nch), dtype=torch.int32, device=dev)
+    # chunk arrivals [row][chunk] + the "workgroups started" count + the per-CU marks
+    cflat = torch.zeros((int(lib.cad_scan_bwd_fold_counter_ints(SB, L)),), dtype=torch.int32, device=dev)
+    counters = cflat[:SB * nch].view(SB, nch)
+    cflat[SB * nch] = G * SB  # "every scan workgroup has been placed": no fold workgroup is in a scan workgroup's way
     aborts = torch.zeros((SB, G), dtype=torch.int32, device=dev)
     a = _fold_args(slots, out, counters, aborts, G, N, SB, L, split, 0, 1)
     CL.check(lib.cad_fold_partials_stream(a, 1, 2, stream), "fold all")
@@ -122,6 +125,7 @@ def test_mixer_layer_gradients_identical_with_and_without_the_stream_fold(backen
     monkeypatch.setattr(mixer, "_STREAM_FOLD", False)
     ref = _layer_grads(mf, mr, hn, g)
     monkeypatch.setattr(mixer, "_STREAM_FOLD", True)
+    monkeypatch.setattr(mixer, "_STREAM_FOLD_MIN_CHUNKS", 1)  # (the emulator's layer has two chunks per row)
     npart = CL.get_lib().cad_scan_bwd_partials(2 * d_model)
     assert ops.fold_stream_supported(16, npart, L, torch.bfloat16), "the layer must take the stream fold"
     got = _layer_grads(mf, mr, hn, g)
@@ -172,3 +176,44 @@ def test_stream_fold_stress_back_to_back_launches(d_model, L, launches):
     finally:
         mixer._STREAM_FOLD = old
         ops.FOLD_GIVE_UPS = None
+
+
+def test_fold_f32_multi_sums_every_job_in_one_launch(backend):
+    """cad_fold_f32_multi: plain folds of different depths and lengths and a two-level fold (the two halves of the tied out_proj's
+    weight gradient added while its K slices are summed) in ONE launch, against fp64 sums of the same data."""
+    name, dev = backend
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn((7, 96, 20), generator=g).to(dev)        # 7 parts of 1920
+    b = torch.randn((33, 8, 16), generator=g).to(dev)        # 33 parts of 128
+    c = torch.randn((5, 2, 12, 16), generator=g).to(dev)     # 5 slices x 2 halves of 192
+    d = torch.randn((1, 64), generator=g).to(dev)            # a single part: a copy
+    outs = [torch.full((96, 20), float("nan"), device=dev), torch.full((8, 16), float("nan"), device=dev),
+            torch.full((12, 16), float("nan"), device=dev), torch.full((64,), float("nan"), device=dev)]
+    ops.fold_f32([(a, outs[0], 1920, 7, 1920, 1, 0), (b, outs[1], 128, 33, 128, 1, 0), (c, outs[2], 192, 5, 384, 2, 192),
+                  (d, outs[3], 64, 1, 64, 1, 0)])
+    want = [a.double().sum(0), b.double().sum(0), c.double().sum((0, 1)), d.double()[0]]
+    for o, w in zip(outs, want):
+        torch.testing.assert_close(o.double(), w, rtol=1e-6, atol=1e-6)
+    # deterministic: the same launch again gives the same bits
+    again = [torch.empty_like(o) for o in outs]
+    ops.fold_f32([(a, again[0], 1920, 7, 1920, 1, 0), (b, again[1], 128, 33, 128, 1, 0), (c, again[2], 192, 5, 384, 2, 192),
+                  (d, again[3], 64, 1, 64, 1, 0)])
+    assert all(torch.equal(x, y) for x, y in zip(outs, again))
+
+
+def test_mixer_layer_glue_fold_matches_the_torch_sums(backend, monkeypatch):
+    """The weight gradients of the production layer with their partial tiles summed by the one own launch (default) and by torch.sum:
+    the same fp32 sums up to the order of the additions."""
+    name, dev = backend
+    d_model, L = (32, 2 * CHUNK) if name == "emu" else (256, 16 * CHUNK)
+    mf, mr, hn, g = _layer(dev, d_model, L)
+    monkeypatch.setattr(mixer, "_GLUE_FOLD", False)
+    ref = _layer_grads(mf, mr, hn, g)
+    monkeypatch.setattr(mixer, "_GLUE_FOLD", True)
+    got = _layer_grads(mf, mr, hn, g)
+    for k in ref:
+        if k == "hn" or "conv1d" in k or k.endswith((".A_log", ".D", ".dt_proj.bias")):
+            tol = dict(rtol=1e-5, atol=1e-5 * float(ref[k].float().abs().max())) if "conv1d" in k and name == "hip" else dict(rtol=0, atol=0)
+            torch.testing.assert_close(got[k].float(), ref[k].float(), **tol)  # not touched by the fold
+        else:
+            torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=2e-6 * float(ref[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")

@@ -323,3 +323,31 @@ def test_asm_hazard_lint_every_kernel(tmp_path):
                 problems.append(f"{os.path.basename(src)} {name[:70]}: {v}")
     assert n_kernels >= 40 and n_asm >= 100, (n_kernels, n_asm)  # the scan kernels alone hold hundreds of asm statements
     assert not problems, "\n".join(problems[:20])
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC) and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_fold_kernel_fits_next_to_two_resident_scan_waves(tmp_path):
+    """The dB / dC fold runs on the CUs WHILE the scan backward occupies them (cad_fold_partials_stream): per SIMD two scan waves + one fold
+    wave must fit the 512-entry register file (allocation granule 8) and the two kernels' LDS the 160 KB of a CU -- held on the compiled
+    resource usage of the production instantiations (a scan kernel that grows past 232 VGPRs, or a fold kernel past 48, would silently
+    serialise the two kernels on the device)."""
+    out = tmp_path / "scan_bwd.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Wno-pass-failed", "-S",
+                           "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "caduceus_amd", "csrc", "scan_bwd.hip")],
+                          stderr=subprocess.DEVNULL)
+    asm = open(out).read()
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+        name, body = m.group(1), m.group(2)
+        vg = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        res[name] = (vg, lds)
+    scan = [v for k, v in res.items() if "scan_bwd_kernelI6bf16_tLb1ELb0ELi8ELb1E" in k]
+    fold = [v for k, v in res.items() if "fold_stream_kernel" in k]
+    gate = [v for k, v in res.items() if "fold_gate_kernel" in k]
+    assert len(scan) == 1 and len(fold) == 1 and len(gate) == 1, list(res)
+    up8 = lambda v: (v + 7) // 8 * 8
+    assert 2 * up8(scan[0][0]) + up8(fold[0][0]) <= 512, (scan, fold)
+    scan_dyn_lds = 135168  # bytes the launcher asks for at the production shape (4 tiles + 2 packed slab buffers + 6 DMA slots)
+    assert scan_dyn_lds + (fold[0][1] + 1279) // 1280 * 1280 <= 160 * 1024, fold
+    assert gate[0][0] <= 16 and gate[0][1] == 0, gate

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end evidence on ONE box: the GPU parity suite, smoke(), counter + trace profiles of the scans (-> bench.SCAN_PMC_FILE = profiles/r05_scan_pmc.json,
+# Round-end evidence on ONE box: the GPU parity suite, smoke(), counter + trace profiles of the scans (-> bench.SCAN_PMC_FILE = profiles/r06_scan_pmc.json,
 # stamped with cad_version()), the whole-step kernel trace, the default bench line and the other configurations' bench lines.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -26,7 +26,10 @@ if f:
     open("gpurun_out/step_trace_final.txt", "w").write("\n".join(out) + "\n")
     print("\n".join(out[:14]))
 PY
-cp gpurun_out/scan_pmc.json profiles/r05_scan_pmc.json  # (on the box: the bench line below quotes the counters taken on THIS build)
+# (round 6: the dB / dC fold runs on a second stream next to the scan backward -- the plain sum above counts its duration in full; what the GPU
+# was busy for, and how much of every kernel ran alone, is the interval union)
+python tools/trace_overlap.py gpurun_out/prof_step/trace 4 > gpurun_out/step_trace_overlap_final.txt 2>&1; head -6 gpurun_out/step_trace_overlap_final.txt | cut -c1-220
+cp gpurun_out/scan_pmc.json profiles/r06_scan_pmc.json  # (on the box: the bench line below quotes the counters taken on THIS build)
 timeout 400 python bench.py > gpurun_out/bench_final.log 2>gpurun_out/bench_final.err; tail -1 gpurun_out/bench_final.log | cut -c1-400
 timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-floor > gpurun_out/bench_final_20steps.log 2>/dev/null; tail -1 gpurun_out/bench_final_20steps.log | cut -c1-200
 if [ "$1" = all ]; then

@@ -47,9 +47,13 @@ def main():
         out = mixer.bimamba_mixer(hn, mf, mr, split)
         out.backward(g)
 
+    from caduceus_amd import ops
+    ops.FOLD_GIVE_UPS = []  # diagnostics: slices the concurrent dB / dC fold left to its cleanup pass (0 when co-scheduled as designed)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    print("fold give-up records in the two warm-up layers:", [int(x) for x in ops.FOLD_GIVE_UPS], file=sys.stderr)
+    ops.FOLD_GIVE_UPS = None
     if a.ab:
         ms = {True: [], False: []}
         for _ in range(a.rounds):

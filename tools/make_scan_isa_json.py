@@ -1,4 +1,4 @@
-"""Static instruction mix of the two production scan kernels (hipcc -S, no GPU needed) -> profiles/r05_scan_isa.json, stamped with the hash of
+"""Static instruction mix of the two production scan kernels (hipcc -S, no GPU needed) -> profiles/r06_scan_isa.json, stamped with the hash of
 the scan sources (caduceus_amd/_build.scan_source_hash) so that bench.py quotes it only for the kernels it was counted on.
     python tools/make_scan_isa_json.py [out.json]"""
 import json
