@@ -809,6 +809,9 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
 // product (library K-split bmm + sum: 0.232): no rotation 0.249 | (37, 11) 0.232 | (53, 29) 0.243 | (19, 5) 0.232 | (45, 77) 0.243 |
 // (27, 32) 0.250 | (64, 16) 0.255 | (1, 32) 0.255 | (3, 1) 0.226 | (3, 64) 0.228 | (1, 0) 0.225 | (4, 1) 0.231 | (5, 2) 0.233 |
 // (7, 3) 0.222 | (2, 1) 0.215 -- and neighbouring workgroups on neighbouring 64-byte pieces (GS_SLICE_INTERLEAVE) 0.303.
+#ifndef GS_XCD_REMAP
+#define GS_XCD_REMAP 1
+#endif
 #ifndef GS_ROT_SL
 #define GS_ROT_SL 2
 #endif
@@ -860,7 +863,13 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_
     const int64_t kper = a.K / a.nslices;            // k range of one slice
     const int nk = (int)(kper / C::KC);              // chunks per work item
     const int64_t nitems = nrt * nct * a.nslices;
-    const int64_t i0 = blockIdx.x, istep = gridDim.x;
+    // XCD-aware start item: the hardware deals workgroup b to XCD b % 8, and the items that share an operand (the row tiles of one weight-
+    // gradient slice read the same B rows; col_fastest: the column tiles of one A tile) are CONSECUTIVE items -- dealt round-robin they
+    // sit on different XCDs and the shared operand crosses HBM once per XCD (profiles/r06_step_pmc_summary.txt: 1079 MB fetched for 671 MB
+    // of operands at the configs[2] weight gradient = B four times).  Workgroup b therefore takes item (b % 8) (grid / 8) + b / 8: every XCD
+    // owns a contiguous run of items, the sharers meet in one L2.
+    const int64_t istep = gridDim.x;
+    const int64_t i0 = (GS_XCD_REMAP && (gridDim.x % 8) == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
     if (i0 >= nitems) return;
     const int64_t nmine = (nitems - i0 + istep - 1) / istep;
     const int64_t total = nmine * nk;

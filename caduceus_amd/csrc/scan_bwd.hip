@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
     constexpr int TILE = SC_TILE(SC_S), ROW = SC_ROW(SC_S);
     const cad_scan_bwd_args& a = sets.s[blockIdx.z];
     float* acc = smem + 4 * TILE;
-    constexpr bool PACKED = SC_SLAB_PACKED && sizeof(T) == 2 && SC_W == 8 && SC_SLAB_BUFS == 2;
+    constexpr bool PACKED = SC_SLAB_PACKED && sizeof(T) == 2 && (SC_W == 8 || SC_W == 4) && SC_SLAB_BUFS == 2;
     uint32_t* accp = (uint32_t*)acc;
     static_assert(!PACKED || SC_S == 8, "packed slab: two 4-item blocks per lane");
     // item vectors of the next chunk travel global -> LDS by DMA one chunk ahead (16-byte vectors: bf16, 8 items)
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 const uint32_t* src = accp + buf * PK_BUF + ten * PK_TILE + (jb * 16 + jl) * 4 + g * (2 * PK_TILE);
                 f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
+                for (int hf = 0; hf < SC_W / 4; ++hf) {  // (K = 32 = four channels x 8 elements per matrix product)
                     const u32x4 b0 = *(const u32x4*)(src + hf * (8 * PK_TILE));
                     const u32x4 b1 = *(const u32x4*)(src + hf * (8 * PK_TILE) + PK_Q);
                     d0 = cad_mfma_16x16x32_bf16(selA, b0, d0);
@@ -719,7 +719,8 @@ __global__ __launch_bounds__(64 * SC_W, SC_OCC) void scan_bwd_kernel(ScanBwdSets
                 // the critical waves' pair-step.  Same-box: 3.391 vs 3.458 ms (-1.9 %); the other half: +1.2 % (profiles/r05_ab_flush_placement.txt).
                 // (NOT unrolled: with both tiles' address arithmetic hoisted out of the chunk loop the kernel spills -- 256 VGPRs + 156 bytes
                 // of scratch, +24 % -- while this form needs 223.)
-                if ((wave < SC_W / 2) == (SC_BWD_FLUSH_HALF == 1)) {  // wave-uniform
+                // (SC_W = 4, two workgroups per CU: every wave stages and flushes -- its own lane block)
+                if (SC_W == 4 || (wave < SC_W / 2) == (SC_BWD_FLUSH_HALF == 1)) {  // wave-uniform
 #pragma unroll 1
                     for (int ften = 0; ften < 2; ++ften) flush_tile(ften, wave & 3);
                 }
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(FOLD_T) void fold_stream_kernel(FoldSets sets, int 
     // with more workgroups than CUs (configs[4]: measured +19 % per layer with one fold workgroup per item).  Items beyond the grid are
     // taken by the same workgroups, item = blockIdx.x + j gridDim.x -- in the order the scan's workgroups are dispatched, and never
     // blocking on one item while another has a chunk ready.
-    __shared__ float part[FOLD_T * 8];
+    __shared__ float part[FOLD_T / 2 * 8];
     __shared__ int nextc[FOLD_MAX_ITEMS];  // next chunk of item j (chunks are taken from the last logical one down); < 0: done
     __shared__ int pick_s[2];              // {item to fold now or -1, give up}
     const int t = threadIdx.x;
@@ -1173,24 +1174,39 @@ __global__ __launch_bounds__(FOLD_T) void fold_stream_kernel(FoldSets sets, int 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) cad_order_point(s[q]);
             }
-            if (grp > 0) {
+        }
+        // group sums through LDS in two rounds (groups 1 .. NG/2 - 1, then NG/2 .. NG - 1): half the staging area -- 4 KB, so that the
+        // workgroup fits behind TWO resident 76 KB scan workgroups (SC_W_BWD = 4) as well as behind one of 132 KB -- same order of additions
+        const int gh = NG / 2;
+        if (active && grp > 0 && grp < gh) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) part[(grp * VPS + v) * 8 + q] = s[q];
-            }
+            for (int q = 0; q < 8; ++q) part[(grp * VPS + v) * 8 + q] = s[q];
         }
         __syncthreads();
         if (active && grp == 0) {
-            float o[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) o[q] = 0.f + s[q];  // (group 0 first: the accumulator of the group sums starts from 0)
+            for (int q = 0; q < 8; ++q) s[q] = 0.f + s[q];  // (group 0 first: the accumulator of the group sums starts from 0)
 #pragma unroll 1
-            for (int g = 1; g < NG; ++g) {  // (not unrolled: the kernel must fit the 48 VGPRs two resident scan waves leave on a SIMD)
+            for (int g = 1; g < gh; ++g) {  // (not unrolled: the kernel must fit the 48 VGPRs two resident scan waves leave on a SIMD)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) o[q] += part[(g * VPS + v) * 8 + q];
+                for (int q = 0; q < 8; ++q) s[q] += part[(g * VPS + v) * 8 + q];
+            }
+        }
+        __syncthreads();
+        if (active && grp > 0 && grp >= gh) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part[((grp - gh) * VPS + v) * 8 + q] = s[q];
+        }
+        __syncthreads();
+        if (active && grp == 0) {
+#pragma unroll 1
+            for (int g = (gh > 1 ? gh : 1); g < NG; ++g) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s[q] += part[((g - gh) * VPS + v) * 8 + q];
             }
             u32x4 ov;
-            ov[0] = cad_pack_bf16x2(o[0], o[1]), ov[1] = cad_pack_bf16x2(o[2], o[3]);
-            ov[2] = cad_pack_bf16x2(o[4], o[5]), ov[3] = cad_pack_bf16x2(o[6], o[7]);
+            ov[0] = cad_pack_bf16x2(s[0], s[1]), ov[1] = cad_pack_bf16x2(s[2], s[3]);
+            ov[2] = cad_pack_bf16x2(s[4], s[5]), ov[3] = cad_pack_bf16x2(s[6], s[7]);
             *(u32x4*)(dbase + row_off * 2u) = ov;
         }
         if (t == 0) nextc[j] = (int)c - 1;
@@ -1239,7 +1255,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     for (int i = 0; i < nsets; ++i) CAD_CHECK_ARG(sets[i].carry_only || !sets[i].fold_counters || vec);  // (16-byte write-through slot stores)
     CadProfScope prof(1, stream);
     dim3 grid((unsigned)((a->E + SC_W - 1) / SC_W), (unsigned)a->SB, (unsigned)nsets), block(64 * SC_W);
-    const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && SC_W == 8 && SC_SLAB_BUFS == 2;
+    const bool packed = SC_SLAB_PACKED && a->dtype == CAD_BF16 && (SC_W == 8 || SC_W == 4) && SC_SLAB_BUFS == 2;
     const bool pref = SC_BWD_PREFETCH && packed && vec && SC_S * 2 == 16;
     bool all_dt = true;  // every set hands over dt itself: the lean production instantiation (ISDT)
     for (int i = 0; i < nsets; ++i) all_dt = all_dt && sets[i].delta_is_dt != 0;
@@ -1249,7 +1265,7 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
     // The lean production instantiation (ISDT) exists only in builds whose tuning defines allow it (its static_assert: LDS-DMA prefetch,
     // packed slab, 8-wave workgroups, unrolled pair loop): in every other variant build (-DSC_BWD_PREFETCH=0, -DSC_SLAB_PACKED=0, -DSC_W_BWD=4,
     // -DSC_BWD_UNROLL_NP=0, -DSC_BWD_LEAN=0) the template argument below is `false` and the branch is the unrolled round-4 kernel again.
-    constexpr bool kLeanBuild = SC_BWD_LEAN && (SC_BWD_UNROLL_NP != 0) && SC_BWD_PREFETCH && SC_SLAB_PACKED && SC_W == 8 && SC_SLAB_BUFS == 2;
+    constexpr bool kLeanBuild = SC_BWD_LEAN && (SC_BWD_UNROLL_NP != 0) && SC_BWD_PREFETCH && SC_SLAB_PACKED && (SC_W == 8 || SC_W == 4) && SC_SLAB_BUFS == 2;
 #define SC_BWD_LAUNCH(T, V)                                                                  \
     do {                                                                                     \
         if (kLeanBuild && SC_BWD_UNROLL_NP && !a->carry_only && V && sizeof(T) == 2 && pref && all_dt &&   \
@@ -1286,6 +1302,21 @@ extern "C" int cad_scan_bwd_multi(const cad_scan_bwd_args* sets, int nsets, void
 
 extern "C" int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream) { return cad_scan_bwd_multi(a, 1, stream); }
 
+// diagnostic (tools/gpu_w4.sh): how many workgroups of the production instantiation the runtime places on one CU, and its LDS bytes
+extern "C" int cad_debug_scan_bwd_occupancy(int* out) {
+#ifndef CAD_EMU
+    const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + 2 * PK_BUF) * sizeof(float) + PRE_BYTES;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_bwd_kernel<bf16_t, true, false, SC_BWD_UNROLL_NP>, 64 * SC_W, shmem) != hipSuccess)
+        return CAD_ERR_LAUNCH;
+    out[0] = nb, out[1] = (int)shmem, out[2] = SC_W;
+    return CAD_OK;
+#else
+    (void)out;
+    return CAD_ERR_UNSUPPORTED;
+#endif
+}
+
 extern "C" int64_t cad_scan_gate_fix_entries(int E, int64_t SB, int64_t L) {
     return (int64_t)E * SB * ((L + SC_CHUNK - 1) / SC_CHUNK);
 }
@@ -1297,7 +1328,10 @@ extern "C" int cad_scan_bwd_gate_fix(const cad_scan_bwd_args* sets, int nsets, v
         if (!a->gate_fix_list) continue;
         CAD_CHECK_ARG(a->gate_fix_count && a->gate_fix_dz && a->z && a->chunk_state);
         CAD_CHECK_ARG(a->E <= (1 << 20) && a->SB <= (1 << 20));
-        dim3 grid(32), block(64 * GF_WAVES);  // an empty or one-entry worklist as a rule: keep the dispatch itself small
+        // an empty or one-entry worklist as a rule (bf16 products: P(z == 0) ~ 4e-9) -- but thousands of entries per launch behind the fp8
+        // in_proj, whose sums of few-bit products cancel EXACTLY far more often: 32 workgroups took 120 us per launch there (3.8 ms per
+        // configs[4] step, profiles/r06_step_trace_c4_fp8.txt), one per CU takes the list in parallel; idle workgroups leave at once
+        dim3 grid((unsigned)cad_cu_count()), block(64 * GF_WAVES);
         if (a->dtype == CAD_F32)
             CAD_LAUNCH((scan_gate_fix_kernel<float>), grid, block, 0, stream, *a);
         else if (a->dtype == CAD_BF16)
@@ -1349,6 +1383,8 @@ extern "C" int cad_fold_stream_supported(int N, int n_partials, int64_t L, int d
     if ((n_partials / CAD_FOLD_GROUP) * vps > FOLD_T) return 0;    // d_state <= 16
     if (FOLD_CHUNK % epw != 0 && epw % FOLD_CHUNK != 0) return 0;  // a slice lies inside one row, or covers whole rows
     if ((N * FOLD_CHUNK) % epw != 0) return 0;                     // ... and inside one tensor
+    // (8-wave workgroups only: the 4-wave variant -- two workgroups per CU, profiles/r06_ab_w4_workgroups.txt -- fails one device test next to
+    // the concurrent fold and is 15 % slower without it)
     return SC_BWD_SLOT_WT && SC_SLAB_PACKED && SC_W == 8 && SC_SLAB_BUFS == 2;  // the write-through slot stores of the packed flush
 }
 

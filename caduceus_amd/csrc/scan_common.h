@@ -29,7 +29,8 @@
 #define SC_W_FWD 8              // waves (= channels) per forward workgroup (measured: 8 beats 4 by 13 %)
 #endif
 #ifndef SC_W_BWD
-#define SC_W_BWD 8              // waves (= channels) per backward workgroup: dB/dC are summed over them in LDS
+#define SC_W_BWD 8              // waves (= channels) per backward workgroup: dB/dC are summed over them in LDS (4 = two workgroups per CU:
+                                // measured 15 % slower, profiles/r06_ab_w4_workgroups.txt)
 #endif
 #ifndef SC_OCC
 #define SC_OCC 2                // register budget: waves per SIMD the kernels are compiled for
