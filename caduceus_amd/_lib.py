@@ -70,6 +70,12 @@ class FoldF32Job(C.Structure):
     _fields_ = [("src", _p), ("dst", _p), ("n", _i64), ("stride", _i64), ("stride2", _i64), ("nparts", _i), ("nparts2", _i)]
 
 
+class GemmF32Args(C.Structure):
+    _fields_ = [("A", _p), ("B", _p), ("D", _p), ("addend", _p), ("M", _i64), ("N", _i64), ("K", _i64),
+                ("a_rs", _i64), ("a_cs", _i64), ("b_rs", _i64), ("b_cs", _i64), ("d_rs", _i64), ("d_cs", _i64),
+                ("batch", _i64), ("a_bs", _i64), ("b_bs", _i64), ("d_bs", _i64)]
+
+
 class Conv1dBwdArgs(C.Structure):
     _fields_ = [("x", _p), ("w", _p), ("bias", _p), ("dout", _p), ("dx", _p), ("dw", _p), ("dbias", _p),
                 ("SB", _i64), ("L", _i64), ("split", _i64), ("E", _i), ("K", _i), ("rev_lo", _i), ("rev_hi", _i),
@@ -173,6 +179,7 @@ SYMBOLS = {
     "cad_gemm_stream": (_i, [C.POINTER(GemmStreamArgs), _p]),
     "cad_gemm_stream_supported": (_i, [_i64, _i64, _i64, _i]),
     "cad_fold_f32_multi": (_i, [C.POINTER(FoldF32Job), _i, _p]),
+    "cad_gemm_f32": (_i, [C.POINTER(GemmF32Args), _p]),
     "cad_quant_rows_fp8": (_i, [C.POINTER(QuantFp8Args), _p]),
     "cad_proj_wxT_fp8": (_i, [C.POINTER(ProjFp8Args), _p]),
     "cad_proj_fp8_supported": (_i, [_i]),

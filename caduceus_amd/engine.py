@@ -12,7 +12,7 @@ duplicated in/out projections.  Here:
   * activations between GEMMs and scans are channel-major (E, S*B, L): the in_proj GEMM writes that layout directly
     (W @ X^T) and every scan/conv access is a contiguous run along L.
 
-On THIS (generic, per-op autograd) path the dense projections are torch.mm / hipBLASLt; the production configuration (tied, "add") runs
+On THIS (generic, per-op autograd) path the dense projections go through ops.mm (fp32: the own cad_gemm_f32; bf16: torch.mm / hipBLASLt); the production configuration (tied, "add") runs
 mixer.BiMambaMixerFn instead, whose projections are the library's own MFMA kernels (csrc/gemm.hip) -- no library GEMM on that step.
 """
 from __future__ import annotations
@@ -37,14 +37,14 @@ def _scan_inputs(xz: torch.Tensor, m, split: int, rev_lo: int, rev_hi: int, act:
     N, R = m.d_state, m.dt_rank
     conv = seqpar.causal_conv1d if seqpar.active() else ops.causal_conv1d
     xc = conv(xz[:E], m.conv1d.weight, m.conv1d.bias, split, rev_lo, rev_hi)
-    dbc = torch.mm(_w(m.x_proj.weight, act), xc.view(E, T)).view(R + 2 * N, SB, L)
-    delta = torch.mm(_w(m.dt_proj.weight, act), dbc[:R].reshape(R, T)).view(E, SB, L)
+    dbc = ops.mm(_w(m.x_proj.weight, act), xc.view(E, T)).view(R + 2 * N, SB, L)
+    delta = ops.mm(_w(m.dt_proj.weight, act), dbc[:R].reshape(R, T)).view(E, SB, L)
     A = -torch.exp(m.A_log.float())
     return (xc, delta, A, dbc[R:R + N], dbc[R + N:], m.D.float(), m.dt_proj.bias.float())
 
 
 def _in_proj(m, x2d: torch.Tensor, SB: int, L: int, act: torch.dtype) -> torch.Tensor:
-    xz = torch.mm(_w(m.in_proj.weight, act), x2d.t())
+    xz = ops.mm(_w(m.in_proj.weight, act), x2d.t())
     if m.in_proj.bias is not None:
         xz = xz + _w(m.in_proj.bias, act).unsqueeze(1)
     return xz.view(-1, SB, L)
@@ -54,7 +54,7 @@ def _out_proj(m, y: torch.Tensor, acc: Optional[torch.Tensor], act: torch.dtype)
     E = y.shape[0]
     yt = y.view(E, -1).t()
     wt = _w(m.out_proj.weight, act).t()
-    out = torch.mm(yt, wt) if acc is None else torch.addmm(acc, yt, wt)
+    out = ops.mm(yt, wt) if acc is None else ops.addmm(acc, yt, wt)
     if m.out_proj.bias is not None:
         out = out + _w(m.out_proj.bias, act)
     return out

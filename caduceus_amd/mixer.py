@@ -91,10 +91,10 @@ def _wgrad_cm_cm(a_cm: torch.Tensor, b_cm: torch.Tensor) -> torch.Tensor:
     if b_cm.shape[0] <= 16 and n >= 64 and T % 16 == 0:
         n = 16  # thin products (dW_dt): fewer, deeper chunks (tools/wgrad_sweep.py: 48 vs 55 us at T = 262144)
     if n == 1:
-        return torch.mm(a_cm, b_cm.t()).float()
+        return ops.mm(a_cm, b_cm.t()).float()
     Kc = T // n
     # (sum with fp32 accumulation straight from the bf16 partial products: no separate up-cast launch)
-    return torch.sum(torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_cm.view(-1, n, Kc).permute(1, 2, 0)), dim=0,
+    return torch.sum(ops.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_cm.view(-1, n, Kc).permute(1, 2, 0)), dim=0,
                      dtype=torch.float32)
 
 
@@ -122,9 +122,9 @@ def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
             return own
     n = _kchunks(T)
     if n == 1:
-        return torch.mm(a_cm, b_tm).float()
+        return ops.mm(a_cm, b_tm).float()
     Kc = T // n
-    return torch.sum(torch.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_tm.view(n, Kc, -1)), dim=0, dtype=torch.float32)
+    return torch.sum(ops.bmm(a_cm.view(M, n, Kc).permute(1, 0, 2), b_tm.view(n, Kc, -1)), dim=0, dtype=torch.float32)
 
 
 # The two scans of a BiMamba layer share the gate z and the upstream gradient: set 0's backward kernel evaluates the gate
@@ -292,7 +292,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             if xz is None and ops.proj_supported(x2d, Dm):  # bf16: the W-stationary MFMA kernel (csrc/gemm.hip) writes channel-major directly
                 xz = ops.proj_wxT(w_in, x2d)
             if xz is None:
-                xz = torch.mm(w_in, x2d.t())
+                xz = ops.mm(w_in, x2d.t())  # fp32: cad_gemm_f32; a bf16 shape no own kernel serves: the library
             xz = xz.view(2 * E, SB, Lq)
         x, z = xz[:E], xz[E:]
         sets, saved = [], []
@@ -320,14 +320,14 @@ class BiMambaMixerFn(torch.autograd.Function):
                 ops.proj_wx(w_x[:, E // 2:], xc.view(E, T)[E // 2:], out=dbc, acc=dbc)
                 dbc = dbc.view(R + 2 * N, SB, Lq)
             else:
-                dbc = torch.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
+                dbc = ops.mm(w_x, xc.view(E, T)).view(R + 2 * N, SB, Lq)
             if ops.proj_wx_supported(xc, R, T):  # thin-K MFMA kernel (transposing LDS reads), csrc/gemm.hip
                 # ... with delta_bias + softplus in its epilogue (fp32): the scans take dt as it is (delta_is_dt)
                 delta = ops.proj_wx(w_dt, dbc[:R].view(R, T),
                                     softplus_bias=dt_bias.float().contiguous() if _FUSED_SOFTPLUS else None).view(E, SB, Lq)
                 fused_sp.append(_FUSED_SOFTPLUS)
             else:
-                delta = torch.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
+                delta = ops.mm(w_dt, dbc[:R].view(R, T)).view(E, SB, Lq)
                 fused_sp.append(False)
             A = cache["A"][i] if cache else -torch.exp(A_log.float())
             sets.append((xc, delta, A, dbc, Dp.float().contiguous(), dt_bias.float().contiguous(), wf, bf, w_x, w_dt))
@@ -362,7 +362,7 @@ class BiMambaMixerFn(torch.autograd.Function):
                 w_out2 = (cache or {}).get("w_out2")
                 out2d = ops.proj_xTw_stream(w_out2 if w_out2 is not None else torch.cat([w_out, w_out], 1), ycat.view(2 * E, T))
             if out2d is None:
-                out2d = torch.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
+                out2d = ops.mm(ycat.view(2 * E, T).t(), torch.cat([w_out, w_out], 1).t())  # W_out (y_f + y_r), tied out_proj
         wT = cache.get("wT") if cache else None
         keep = [x2d, xz, w_in, w_out, ycat]
         for i in range(2):
@@ -394,7 +394,7 @@ class BiMambaMixerFn(torch.autograd.Function):
         if dy is None and ops.proj_supported(dout2d, Dm):
             dy = ops.proj_wxT(wT["out"] if wT else w_out.t().contiguous(), dout2d)
         if dy is None:
-            dy = torch.mm(w_out.t(), dout2d.t())
+            dy = ops.mm(w_out.t(), dout2d.t())
         dy = dy.view(E, SB, Lq)
         y_f, y_r = ycat[:E], ycat[E:]
         glue = []  # (src, dst, n, nparts, stride, nparts2, stride2) jobs of the one fp32 fold launch at the end (_GLUE_FOLD)
@@ -505,7 +505,7 @@ class BiMambaMixerFn(torch.autograd.Function):
                 if ops.proj_wx_supported(ddelta, E, T, M=R):
                     ops.proj_wx(wT["dt"][i] if wT else w_dt.t().contiguous(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
                 else:
-                    torch.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
+                    ops.mm(w_dt.t(), ddelta.view(E, T), out=ddbc[:R].view(R, T))
                 if _OWN_DWX and _own_wgrad_chunked_ok(ddelta.view(E, T), R):
                     dW_dt = _own_wgrad_chunked(ddelta.view(E, T), dbc[:R].view(R, T)).t()
                 else:
@@ -524,7 +524,10 @@ class BiMambaMixerFn(torch.autograd.Function):
                 ops.proj_wx(wT["x"][i] if wT else w_x.t().contiguous(), ddbc.view(R + 2 * N, T), out=du.view(E, T),
                             acc=du.view(E, T))
             else:
-                du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))
+                if du.dtype == torch.float32:
+                    ops.mm_f32(w_x.t(), ddbc.view(R + 2 * N, T), out=du.view(E, T), addend=du.view(E, T))
+                else:
+                    du.view(E, T).addmm_(w_x.t(), ddbc.view(R + 2 * N, T))
             dxcs.append(du)
             part.append((dW_x, dW_dt, dbias, dA * A, dD))  # A = -exp(A_log)  =>  dA/dA_log = A
         if CAPTURE_XPROJ_OPERANDS is not None:
@@ -559,7 +562,7 @@ class BiMambaMixerFn(torch.autograd.Function):
             w_inT = wT["in"] if (wT and wT.get("in") is not None) else w_in.t().contiguous()
             dx2d = ops.proj_xTw_stream(w_inT, dxz.view(2 * E, T))
         if dx2d is None:
-            dx2d = torch.mm(dxz.view(2 * E, T).t(), w_in)
+            dx2d = ops.mm(dxz.view(2 * E, T).t(), w_in)
         part_in = None
         if _GLUE_FOLD and _OWN_GEMM and (Dm <= 256 or _OWN_GEMM_D512):
             part_in = ops.wgrad_cm_tm(dxz.view(2 * E, T), x2d, return_partials=True)

@@ -346,7 +346,11 @@ class CaduceusForMaskedLM(CaduceusPreTrainedModel):
             if w.shape[0] <= 16 and getattr(self.lm_head, "bias", None) is None:
                 logits, loss = ops.lm_head(hidden_t, w, None, labels if fused_loss else None, ignore_index)
             else:
-                logits = F.linear(hidden_t[0], w.to(hidden_t.dtype), self.lm_head.bias).float()
+                h0 = hidden_t[0]
+                logits = ops.mm(h0.reshape(-1, h0.shape[-1]), w.to(hidden_t.dtype).t()).view(*h0.shape[:-1], w.shape[0])
+                if self.lm_head.bias is not None:
+                    logits = logits + self.lm_head.bias.to(logits.dtype)
+                logits = logits.float()
                 loss = cross_entropy(logits, labels, ignore_index=ignore_index) if fused_loss else None
         if labels is not None and loss_weights is not None:
             loss = weighted_cross_entropy(logits, labels, loss_weights, ignore_index=ignore_index)

@@ -161,9 +161,11 @@ class RCPSLMHead(nn.Module):
         if self.lm_head.bias is not None:
             raise NotImplementedError("RCPSLMHead is bias-free in the reference")
         V = self.lm_head.weight.shape[0]
-        if V > 16:  # large vocabularies: a real GEMM, goes to hipBLASLt
+        if V > 16:  # large vocabularies: a real GEMM (fp32: cad_gemm_f32; bf16: hipBLASLt)
             w = self.lm_head.weight.to(hidden.dtype)
-            logits = (hidden[0] @ w.t() + hidden[1] @ w[self.complement_map].t()).float()
+            D = hidden.shape[-1]
+            logits = ops.addmm(ops.mm(hidden[0].reshape(-1, D), w.t()), hidden[1].reshape(-1, D), w[self.complement_map].t())
+            logits = logits.view(*hidden.shape[1:-1], V).float()
             loss = None
             if labels is not None:
                 loss = torch.nn.functional.cross_entropy(logits.view(-1, V), labels.view(-1), ignore_index=ignore_index)

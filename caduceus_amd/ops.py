@@ -640,11 +640,11 @@ class _LmHead(torch.autograd.Function):
         h = hidden.reshape(S, -1, D)
         dh = torch.empty_like(h)
         wt = w.to(hidden.dtype)
-        dh[0] = gt @ wt
-        dw = gt.t().float() @ h[0].float() if h.dtype == torch.float32 else (gt.t() @ h[0]).float()
+        dh[0] = mm(gt, wt)
+        dw = mm(gt.t(), h[0]).float()
         if S == 2:
-            dh[1] = gt @ wt[comp]
-            d2 = (gt.t() @ h[1]).float()
+            dh[1] = mm(gt, wt[comp])
+            d2 = mm(gt.t(), h[1]).float()
             dw.index_add_(0, comp, d2)
         return dh.reshape(hidden.shape), dw.to(wdt), None, None, None
 
@@ -659,6 +659,144 @@ def lm_head(hidden: torch.Tensor, weight: torch.Tensor, comp: Optional[torch.Ten
 # ------------------------------------------------------------------------------------------------------------------
 # dense projections on the matrix cores (raw ops, no autograd: caduceus_amd/mixer.py schedules their gradients by hand)
 # ------------------------------------------------------------------------------------------------------------------
+def mm_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (M, N) fp32 = [addend +] a (M, K) @ b (K, N) on the fp32 matrix core (cad_gemm_f32) -- torch.mm / torch.addmm for the fp32 path
+    without a library GEMM.  a / b: 2-D fp32 views with ONE unit stride each (plain or transposed, any row pitch: the channel-major and
+    token-major views of the mixer are taken as they are); out: any 2-D fp32 view (default: a new contiguous tensor); addend: out's
+    strides (or out itself).  A product with a small result and a long reduction (a weight gradient over all tokens: 1024 x 256 from
+    K = 262144) is cut into K slices -- one launch, fp32 partial tiles, one fp32 sum -- for the same two reasons as on the bf16 path:
+    16 output tiles cannot fill 256 CUs, and 64 partial sums of 4096 terms round better than one chain of 262144.  The batched form is
+    bmm_f32."""
+    if a.dim() != 2 or b.dim() != 2:
+        raise ValueError("mm_f32: 2-D operands")
+    M, K = a.shape
+    N = b.shape[1] if b.dim() == 2 else 0
+    n = _f32_kslices(M, N, K) if b.shape[0] == K else 1
+    if n > 1:
+        Kc = K // n
+        part = _gemm_f32(a.unflatten(1, (n, Kc)).permute(1, 0, 2), b.unflatten(0, (n, Kc)), None, None)  # (n, M, N)
+        res = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        if (M * N) % 4 == 0:
+            fold_f32([(part, res, M * N, n, M * N, 1, 0)])
+        else:
+            torch.sum(part, dim=0, out=res)
+        if addend is not None:
+            res = res + addend
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
+    return _gemm_f32(a.unsqueeze(0), b.unsqueeze(0), None if out is None else out.unsqueeze(0),
+                     None if addend is None else addend.unsqueeze(0))[0]
+
+
+def _f32_kslices(M: int, N: int, K: int) -> int:
+    """K slices of an fp32 product (1: none): only when the 128 x 128 result tiles are too few to fill the chip and every slice keeps
+    at least 1024 terms."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    n = 1
+    while tiles * n < 256 and n < 64 and K % (2 * n) == 0 and K // (2 * n) >= 1024:
+        n *= 2
+    return n
+
+
+def bmm_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (n, M, N) fp32 = a (n, M, K) @ b (n, K, N), one launch (cad_gemm_f32, blockIdx.z = batch); a / b: 3-D fp32 views, one unit
+    stride among the two inner dimensions of each."""
+    return _gemm_f32(a, b, out, None)
+
+
+def _gemm_f32(a, b, out, addend):
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.dim() != 3 or b.dim() != 3:
+        raise ValueError("gemm_f32: fp32 operands, (n, M, K) @ (n, K, N)")
+    n, M, K = a.shape
+    N = b.shape[2]
+    if b.shape[0] != n or b.shape[1] != K:
+        raise ValueError(f"gemm_f32: shapes {tuple(a.shape)} @ {tuple(b.shape)}")
+
+    def strides(t):
+        """(row, column) element strides the kernel needs: one of them 1.  The stride of a size-1 dimension is never used: report it as
+        the unit one when the other is not; a matrix with two non-unit strides is copied."""
+        rs, cs = t.stride(1), t.stride(2)
+        if t.shape[1] == 1 and cs != 1:
+            rs = 1
+        elif t.shape[2] == 1 and rs != 1:
+            cs = 1
+        if rs != 1 and cs != 1:
+            t = t.contiguous()
+            rs, cs = t.stride(1), t.stride(2)
+            if cs != 1:  # (n, M, 1) contiguous: strides (M, 1, 1) -- cannot happen; kept as a guard
+                raise ValueError("gemm_f32: operand without a unit stride")
+        return t, rs, cs
+
+    a, a_rs, a_cs = strides(a)
+    b, b_rs, b_cs = strides(b)
+    if out is None:
+        out = torch.empty((n, M, N), dtype=torch.float32, device=a.device)
+    if out.dtype != torch.float32 or tuple(out.shape) != (n, M, N):
+        raise ValueError("gemm_f32: out must be fp32 (n, M, N)")
+    if addend is not None and (addend.dtype != torch.float32 or addend.shape != out.shape or addend.stride() != out.stride()):
+        raise ValueError("gemm_f32: addend must have out's dtype, shape and strides")
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        if addend is None:
+            out.zero_()
+        elif addend.data_ptr() != out.data_ptr():
+            out.copy_(addend)
+        return out
+    stream = L.stream_and_check(a, b, out, contiguous=False)
+    bs = lambda t: t.stride(0) if n > 1 else 0
+    args = L.GemmF32Args(L.ptr(a), L.ptr(b), L.ptr(out), None if addend is None else L.ptr(addend), M, N, K,
+                         a_rs, a_cs, b_rs, b_cs, max(out.stride(1), 1), max(out.stride(2), 1), n, bs(a), bs(b), bs(out))
+    L.check(L.get_lib().cad_gemm_f32(C.byref(args), stream), "cad_gemm_f32")
+    return out
+
+
+class _MmF32(torch.autograd.Function):
+    """a @ b (+ addend) in fp32 on cad_gemm_f32, differentiable: da = g @ b^T, db = a^T @ g through the same kernel (transposed views)."""
+
+    @staticmethod
+    def forward(ctx, a, b, addend):
+        ctx.save_for_backward(a, b)
+        return mm_f32(a, b, addend=addend)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = mm_f32(g, b.t()) if ctx.needs_input_grad[0] else None
+        db = mm_f32(a.t(), g) if ctx.needs_input_grad[1] else None
+        return da, db, (g if ctx.needs_input_grad[2] else None)
+
+
+def _own_f32(*ts) -> bool:
+    return all(t.dtype == torch.float32 for t in ts)
+
+
+def mm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch.mm for the call sites that have no dedicated kernel: fp32 operands take the own fp32 matrix-core kernel (cad_gemm_f32;
+    differentiable), anything else (bf16 shapes the MFMA projection kernels do not serve) the library."""
+    if _own_f32(a, b):
+        if out is not None:
+            return mm_f32(a, b, out=out)
+        return _MmF32.apply(a, b, None)
+    return torch.mm(a, b) if out is None else torch.mm(a, b, out=out)
+
+
+def addmm(acc: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """acc + a @ b (torch.addmm), fp32 on the own kernel."""
+    if _own_f32(acc, a, b):
+        return _MmF32.apply(a, b, acc)
+    return torch.addmm(acc, a, b)
+
+
+def bmm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.bmm (no autograd use in this package), fp32 on the own kernel."""
+    if _own_f32(a, b):
+        return bmm_f32(a, b)
+    return torch.bmm(a, b)
+
+
 def proj_supported(t: torch.Tensor, K: int) -> bool:
     """The MFMA projection kernels take bf16 operands with a supported reduction length.  (K = 512, d_model 512: stand-alone and cold the
     library GEMM is 18-25 % faster than the W-stationary kernel, inside the training step it is not -- 558.9 vs 555.9 ms per step;

@@ -454,6 +454,25 @@ typedef struct {
     int nparts, nparts2;
 } cad_fold_f32_job;
 int cad_fold_f32_multi(const cad_fold_f32_job* jobs, int njobs, void* stream);
+
+/* cad_gemm_f32: D (M x N) = [addend +] A (M x K) . B (K x N), fp32 operands, fp32 accumulation, fp32 result, on the fp32 matrix core
+ * (v_mfma_f32_16x16x4_f32): the dense projections of the fp32 path -- the F.linear / matmul calls of mamba_inner_fn
+ * (/root/reference/caduceus/modeling_caduceus.py:11,128,130: in_proj, x_proj, dt_proj, out_proj and their gradients) when the model runs in
+ * fp32 (BASELINE configs[0]; the reference's fp16-AMP activations are computed by the same fp32 kernels here), which went through torch.mm
+ * (hipBLASLt) until round 6.  Element (i, j) of an operand X is X[i * x_rs + j * x_cs] (elements; for A and B one of the two strides must
+ * be 1), so transposed and channel-major views need no copy.  `batch` independent products, operands / results *_bs elements apart (the
+ * K slices of a weight gradient over all tokens: partial tiles, summed by the caller in fp32).  addend (optional, may be D itself) has D's
+ * layout.  Any M, N, K >= 1. */
+typedef struct {
+    const float* A;
+    const float* B;
+    float* D;
+    const float* addend;
+    int64_t M, N, K;
+    int64_t a_rs, a_cs, b_rs, b_cs, d_rs, d_cs;
+    int64_t batch, a_bs, b_bs, d_bs;
+} cad_gemm_f32_args;
+int cad_gemm_f32(const cad_gemm_f32_args* a, void* stream);
 int cad_gemm_stream_supported(int64_t R, int64_t C, int64_t K, int nslices);
 
 /* ---------------------------------------------------------------------------------------------------------

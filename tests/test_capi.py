@@ -64,7 +64,8 @@ def test_ctypes_structs_mirror_header():
               "cad_lm_head_args": _lib.LmHeadArgs, "cad_lm_head_bwd_args": _lib.LmHeadBwdArgs, "cad_mlm_args": _lib.MlmArgs,
               "cad_proj_args": _lib.ProjArgs, "cad_quant_fp8_args": _lib.QuantFp8Args,
               "cad_proj_fp8_args": _lib.ProjFp8Args, "cad_proj_tm_args": _lib.ProjTmArgs, "cad_reduce_job": _lib.ReduceJob,
-              "cad_gemm_stream_args": _lib.GemmStreamArgs, "cad_fold_args": _lib.FoldArgs, "cad_fold_f32_job": _lib.FoldF32Job}
+              "cad_gemm_stream_args": _lib.GemmStreamArgs, "cad_fold_args": _lib.FoldArgs, "cad_fold_f32_job": _lib.FoldF32Job,
+              "cad_gemm_f32_args": _lib.GemmF32Args}
     assert set(hs) == set(mirror)
     for name, cls in mirror.items():
         assert [f[0] for f in cls._fields_] == hs[name], name
@@ -86,7 +87,8 @@ def test_struct_sizes_match_compiler(tmp_path):
               "cad_lm_head_args": _lib.LmHeadArgs, "cad_lm_head_bwd_args": _lib.LmHeadBwdArgs, "cad_mlm_args": _lib.MlmArgs,
               "cad_proj_args": _lib.ProjArgs, "cad_quant_fp8_args": _lib.QuantFp8Args,
               "cad_proj_fp8_args": _lib.ProjFp8Args, "cad_proj_tm_args": _lib.ProjTmArgs, "cad_reduce_job": _lib.ReduceJob,
-              "cad_gemm_stream_args": _lib.GemmStreamArgs, "cad_fold_args": _lib.FoldArgs, "cad_fold_f32_job": _lib.FoldF32Job}
+              "cad_gemm_stream_args": _lib.GemmStreamArgs, "cad_fold_args": _lib.FoldArgs, "cad_fold_f32_job": _lib.FoldF32Job,
+              "cad_gemm_f32_args": _lib.GemmF32Args}
     for n, cls in mirror.items():
         assert int(sizes[n]) == ctypes.sizeof(cls), n
 

@@ -134,15 +134,19 @@ def test_tokenizer_ids_and_complement_map():
     CaduceusTokenizer(model_max_length=16, add_special_tokens=False)  # the reference's constructor call (genomics.py:108-111)
 
 
-def test_chunked_weight_gradient_gemms_match_plain_mm():
-    """caduceus_amd/mixer.py: the K-chunked strided-batch formulation of the weight gradients is the same product."""
+def test_chunked_weight_gradient_gemms_match_plain_mm(backend):
+    """caduceus_amd/mixer.py: the K-chunked strided-batch formulation of the weight gradients is the same product (fp32 operands: the
+    batched cad_gemm_f32 since round 6 -- on the emulator here, on the device under -m gpu; bf16 operands: the library bmm)."""
     from caduceus_amd import mixer
+    name, dev = backend
     g = torch.Generator().manual_seed(0)
     T = 8192
     assert mixer._kchunks(T) == 8 and mixer._kchunks(262144) == 64 and mixer._kchunks(100) == 1
     a, b_cm, b_tm = torch.randn(24, T, generator=g), torch.randn(10, T, generator=g), torch.randn(T, 12, generator=g)
-    torch.testing.assert_close(mixer._wgrad_cm_cm(a, b_cm), a @ b_cm.t(), rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(mixer._wgrad_cm_tm(a, b_tm), a @ b_tm, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(mixer._wgrad_cm_cm(a.to(dev), b_cm.to(dev)).cpu(), a @ b_cm.t(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(mixer._wgrad_cm_tm(a.to(dev), b_tm.to(dev)).cpu(), a @ b_tm, rtol=1e-4, atol=1e-3)
+    ab, bb = a.to(torch.bfloat16), b_cm.to(torch.bfloat16)
+    torch.testing.assert_close(mixer._wgrad_cm_cm(ab.to(dev), bb.to(dev)).cpu(), ab.float() @ bb.float().t(), rtol=2e-2, atol=0.5)
 
 
 def test_bench_quotes_a_counter_profile_only_for_the_profiled_scan_sources():

@@ -46,6 +46,36 @@ def test_model_matches_reference_fp32(backend, name):
     assert checked > 10
 
 
+@pytest.mark.parametrize("name", MODEL_VARIANTS)
+def test_fp32_training_step_runs_without_a_library_gemm(backend, name, monkeypatch):
+    """The fp32 path (north_star's "stated fp32 tolerance"; BASELINE configs[0]'s precision) multiplies on the own fp32 matrix-core kernel
+    (cad_gemm_f32, csrc/gemm_f32.hip) since round 6: forward + loss + backward of every golden variant -- tied / un-tied, add / ew_multiply,
+    uni-directional, LayerNorm, odd sizes: the hand-scheduled mixer AND the generic per-op engine -- with the torch matrix products made
+    to raise, held to the reference's logits, loss and gradients at the reference tolerance."""
+    _, dev = backend
+    model, cfg, sd, rec = build_model(name, dev)
+    ids, labels = rec["input_ids"].to(dev), rec["labels"].to(dev)
+
+    def boom(*a, **k):
+        raise AssertionError("a library matrix product on the fp32 path")
+
+    with monkeypatch.context() as mp:
+        for fn in ("mm", "bmm", "addmm", "matmul", "baddbmm", "einsum"):
+            mp.setattr(torch, fn, boom)
+        mp.setattr(torch.Tensor, "__matmul__", boom)
+        mp.setattr(torch.Tensor, "addmm_", boom)
+        mp.setattr(torch.nn.functional, "linear", boom)
+        out = model(ids, labels=labels)
+        out.loss.backward()
+    torch.testing.assert_close(out.logits.cpu(), rec["logits"], **FP32)
+    torch.testing.assert_close(out.loss.cpu(), rec["loss"], **FP32)
+    named = model.state_dict(keep_vars=True)
+    for k, g in rec.items():
+        if k.startswith("grad/"):
+            scale = max(1.0, float(g.abs().max()))
+            torch.testing.assert_close(named[k[5:]].grad.cpu(), g, rtol=6e-4, atol=2e-3 * scale, msg=lambda m, k=k: f"{k}: {m}")
+
+
 @pytest.mark.parametrize("name", ["ps_fused", "ps_unfused", "ph_fused"])
 def test_layer_trace_matches_reference(backend, name):
     """Per-layer (hidden, residual) of the reference, through the module-level reference-frame API."""

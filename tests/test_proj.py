@@ -442,3 +442,56 @@ def test_gemm_out_t_as_a_projection_with_column_tiles_fastest(backend, M, K, T):
     perm = torch.randperm(T, generator=torch.Generator().manual_seed(6))
     out_p = ops.gemm_out_t(X[perm].contiguous().to(dev), Wt.to(dev))
     assert torch.equal(out.cpu()[:, perm], out_p.cpu())
+
+
+# ---- cad_gemm_f32: the fp32 path's dense products on the fp32 matrix core (csrc/gemm_f32.hip) ---------------------------------------
+def _f32(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (40, 70, 128), (128, 128, 16), (130, 257, 33), (512, 96, 8), (48, 300, 256), (200, 64, 1000)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_f32_matches_fp64_product(backend, M, N, K, ta, tb):
+    """Every combination of plain / transposed operand views (the mixer's W . X^T, X^T . W^T, Y . X^T), ragged sizes: tile edges in all
+    three dimensions.  fp32 products accumulated in fp32: the bound is the fp32 class of the reference (rtol 6e-4 is ITS parity bound;
+    measured ~1e-6 relative to the result's scale)."""
+    name, dev = backend
+    a = (_f32(K, M, seed=1).t() if ta else _f32(M, K, seed=1))
+    b = (_f32(N, K, seed=2).t() if tb else _f32(K, N, seed=2))
+    out = ops.mm_f32(a.to(dev) if not ta else a.t().contiguous().to(dev).t(), b.to(dev) if not tb else b.t().contiguous().to(dev).t())
+    ref = a.double() @ b.double()
+    assert out.shape == (M, N) and out.dtype == torch.float32
+    scale = float(ref.abs().max()) + 1e-30
+    assert float((out.cpu().double() - ref).abs().max()) / scale < 2e-6 * max(1.0, K ** 0.5 / 8)
+
+
+def test_gemm_f32_addend_out_views_and_batches(backend):
+    name, dev = backend
+    M, N, K, n = 70, 90, 50, 3
+    a, b, c = _f32(M, K, seed=3), _f32(K, N, seed=4), _f32(M, N, seed=5)
+    # addend + a padded out view (token-major column slice): the bytes outside the view stay untouched
+    buf = torch.full((M, N + 6), 7.0, device=dev)
+    add = torch.zeros((M, N + 6), device=dev)
+    add[:, :N] = c.to(dev)
+    ops.mm_f32(a.to(dev), b.to(dev), out=buf[:, :N], addend=add[:, :N])
+    torch.testing.assert_close(buf[:, :N].cpu(), c + a @ b, rtol=1e-5, atol=1e-4)
+    assert float((buf[:, N:] - 7.0).abs().max()) == 0.0
+    # in-place accumulate (addend is out)
+    acc = c.clone().to(dev)
+    ops.mm_f32(a.to(dev), b.to(dev), out=acc, addend=acc)
+    torch.testing.assert_close(acc.cpu(), c + a @ b, rtol=1e-5, atol=1e-4)
+    # a transposed OUT view: D^T written through strides
+    outT = torch.empty(N, M, device=dev)
+    ops.mm_f32(a.to(dev), b.to(dev), out=outT.t())
+    torch.testing.assert_close(outT.cpu(), (a @ b).t(), rtol=1e-5, atol=1e-4)
+    # batches = the K slices of a weight gradient: (n, M, Kc) permuted views of channel-major operands, as mixer._wgrad_cm_cm builds them
+    Kc = 64
+    y, x = _f32(M, n * Kc, seed=6), _f32(N, n * Kc, seed=7)
+    part = ops.bmm_f32(y.to(dev).view(M, n, Kc).permute(1, 0, 2), x.to(dev).view(N, n, Kc).permute(1, 2, 0))
+    assert part.shape == (n, M, N)
+    torch.testing.assert_close(part.sum(0).cpu(), y @ x.t(), rtol=1e-5, atol=2e-4)
+    with pytest.raises(ValueError):
+        ops.mm_f32(a.to(dev).to(torch.bfloat16), b.to(dev))
+    with pytest.raises(ValueError):
+        ops.mm_f32(a.to(dev), b.to(dev)[:-1])

@@ -20,7 +20,7 @@ KERNELS = {  # production instantiations: bf16, vector path, d_state 16 (unrolle
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_scan_isa.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_scan_isa.json")
     res = {"source": "tools/make_scan_isa_json.py: hipcc --offload-arch=gfx950 -O3 -S of csrc/scan_*.hip, instructions of the basic blocks inside the "
                      "chunk loop of each production instantiation, counted statically over ALL paths (a wave executes one direction's store "
                      "variant and one gate variant of them: the executed count per chunk is lower; rocprofv3 SQ_INSTS_VALU / SQ_WAVES is the "
