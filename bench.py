@@ -521,9 +521,9 @@ def main():
             # the kernel the product path DISPATCHES for the in_proj of this width (mixer.BiMambaMixerFn.forward): d_model > 256 ->
             # cad_gemm_stream with both operands streamed (B = W_in^T from the step cache), else the W-stationary cad_proj_wxT
             from caduceus_amd import mixer as _mixer
-            own = _ops.proj_supported(xx, args.d_model)  # (csrc/gemm.hip), else hipBLASLt
-            kname = "cad_proj_wxT, own bf16 MFMA kernel" if own else "hipBLASLt"
-            run = (lambda: _ops.proj_wxT(ww, xx)) if own else (lambda: torch.mm(ww, xx.t()))
+            own = _ops.proj_supported(xx, args.d_model)  # (csrc/gemm.hip); fp32: the fp32 matrix-core kernel (csrc/gemm_f32.hip); else hipBLASLt
+            kname = "cad_proj_wxT, own bf16 MFMA kernel" if own else ("cad_gemm_f32, own fp32 MFMA kernel" if amp == torch.float32 else "hipBLASLt")
+            run = (lambda: _ops.proj_wxT(ww, xx)) if own else (lambda: _ops.mm(ww, xx.t()))
             if _mixer._STREAM_PROJ_D512 and args.d_model > 256 and amp == torch.bfloat16:
                 wwT = ww.t().contiguous()
                 if _ops.gemm_out_t(xx, wwT) is not None:

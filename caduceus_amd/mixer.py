@@ -87,6 +87,8 @@ def _kchunks(T: int) -> int:
 def _wgrad_cm_cm(a_cm: torch.Tensor, b_cm: torch.Tensor) -> torch.Tensor:
     """a (M, T) @ b (N, T)^T with both operands channel-major (T contiguous) -> (M, N) fp32."""
     M, T = a_cm.shape
+    if a_cm.dtype == torch.float32:  # the own fp32 matrix-core kernel cuts K itself (ops.mm_f32)
+        return ops.mm_f32(a_cm, b_cm.t())
     n = _kchunks(T)
     if b_cm.shape[0] <= 16 and n >= 64 and T % 16 == 0:
         n = 16  # thin products (dW_dt): fewer, deeper chunks (tools/wgrad_sweep.py: 48 vs 55 us at T = 262144)
@@ -120,6 +122,8 @@ def _wgrad_cm_tm(a_cm: torch.Tensor, b_tm: torch.Tensor) -> torch.Tensor:
         own = ops.wgrad_cm_tm(a_cm, b_tm)
         if own is not None:
             return own
+    if a_cm.dtype == torch.float32:
+        return ops.mm_f32(a_cm, b_tm)
     n = _kchunks(T)
     if n == 1:
         return ops.mm(a_cm, b_tm).float()

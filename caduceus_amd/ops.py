@@ -691,11 +691,11 @@ def mm_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
 
 
 def _f32_kslices(M: int, N: int, K: int) -> int:
-    """K slices of an fp32 product (1: none): only when the 128 x 128 result tiles are too few to fill the chip and every slice keeps
-    at least 1024 terms."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    """K slices of an fp32 product (1: none): only when the result tiles (64 x 64, the kernel's small configuration) are too few to fill
+    the chip and every slice keeps at least 256 terms."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
     n = 1
-    while tiles * n < 256 and n < 64 and K % (2 * n) == 0 and K // (2 * n) >= 1024:
+    while tiles * n < 256 and n < 64 and K % (2 * n) == 0 and K // (2 * n) >= 256:
         n *= 2
     return n
 

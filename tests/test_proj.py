@@ -466,6 +466,21 @@ def test_gemm_f32_matches_fp64_product(backend, M, N, K, ta, tb):
     assert float((out.cpu().double() - ref).abs().max()) / scale < 2e-6 * max(1.0, K ** 0.5 / 8)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, True)])
+def test_gemm_f32_large_tile_configuration(backend, ta, tb):
+    """Enough 128 x 128 tiles to fill the chip (>= 2 per CU): the launcher takes the 4 x 4-tiles-per-wave configuration -- ragged edges in
+    every dimension, plain and transposed views."""
+    name, dev = backend
+    M, N, K = 2048 + 40, 4096 + 5, 21
+    a = (_f32(K, M, seed=8).t() if ta else _f32(M, K, seed=8))
+    b = (_f32(N, K, seed=9).t() if tb else _f32(K, N, seed=9))
+    ad = a.t().contiguous().to(dev).t() if ta else a.to(dev)
+    bd = b.t().contiguous().to(dev).t() if tb else b.to(dev)
+    out = ops.mm_f32(ad, bd)
+    ref = a.double() @ b.double()
+    assert float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+
+
 def test_gemm_f32_addend_out_views_and_batches(backend):
     name, dev = backend
     M, N, K, n = 70, 90, 50, 3
