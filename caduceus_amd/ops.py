@@ -691,11 +691,16 @@ def mm_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
 
 
 def _f32_kslices(M: int, N: int, K: int) -> int:
-    """K slices of an fp32 product (1: none): only when the result tiles (64 x 64, the kernel's small configuration) are too few to fill
-    the chip and every slice keeps at least 256 terms."""
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    """K slices of an fp32 product (1: none), chosen with the launcher's two tile configurations in mind (csrc/gemm_f32.hip): a result of
+    at least eight 128 x 128 tiles is cut until two such tiles per CU exist (slices of >= 1024 terms) and runs on the large
+    configuration; a smaller one is cut until its 64 x 64 tiles fill the chip (slices of >= 256 terms)."""
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if M > 64 and N > 64 and t128 >= 8:
+        tiles, want, least = t128, 2 * _cu_count(), 1024
+    else:
+        tiles, want, least = ((M + 63) // 64) * ((N + 63) // 64), _cu_count(), 256
     n = 1
-    while tiles * n < 256 and n < 64 and K % (2 * n) == 0 and K // (2 * n) >= 256:
+    while tiles * n < want and n < 64 and K % (2 * n) == 0 and K // (2 * n) >= least:
         n *= 2
     return n
 
