@@ -5,9 +5,9 @@
 #include "cad_common.h"
 
 // A build with -D tuning defines says so (CAD_VARIANT = the define list, caduceus_amd/_build.py); a build whose kernels were cut down for
-// TIMING experiments (-DSC_WHATIF=<bits> / -DSC_TIMING: wrong results by construction) carries the marker the loader refuses
+// TIMING experiments (-DSC_WHATIF=<bits> / -DSC_TIMING / -DGS_WHATIF=<bits>: wrong results by construction) carries the marker the loader refuses
 // (caduceus_amd/_lib.py: only with CADUCEUS_AMD_ALLOW_TIMING_BUILD=1, which bench.py's floor worker and the A/B tools set).
-#if (defined(SC_WHATIF) && SC_WHATIF != 0) || defined(SC_TIMING)
+#if (defined(SC_WHATIF) && SC_WHATIF != 0) || defined(SC_TIMING) || (defined(GS_WHATIF) && GS_WHATIF != 0)
 #define CAD_TIMING_TAG " TIMING-BUILD (wrong results by construction; never the product)"
 #else
 #define CAD_TIMING_TAG ""

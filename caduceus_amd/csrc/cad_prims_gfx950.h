@@ -222,6 +222,13 @@ __device__ __forceinline__ uint64_t cad_wall_clock_hz() { return 100000000ull; }
         }                                                                                                            \
     } while (0)
 
+// workgroups of `kern` the runtime places on one CU (0 on failure): a diagnostic for the launch-shape experiments
+#define CAD_OCCUPANCY(kern, threads, bytes)                                                                          \
+    ([&]() {                                                                                                         \
+        int nb_ = 0;                                                                                                 \
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (kern), (threads), (bytes)) == hipSuccess ? nb_ : 0; \
+    }())
+
 // ---- fp8 (OCP e4m3) ------------------------------------------------------------------------------------------------------------------
 // four fp32 -> four e4m3 bytes (element j in byte j)
 __device__ __forceinline__ uint32_t cad_pack_fp8x4(float a, float b, float c, float d) {

@@ -812,6 +812,12 @@ __global__ __launch_bounds__(64 * GP_WAVES, 2) void proj_xTw_kernel(cad_proj_tm_
 #ifndef GS_XCD_REMAP
 #define GS_XCD_REMAP 1
 #endif
+// timing experiments only (WRONG results; the library says TIMING-BUILD): 1 = no fragment reads / MFMAs (what do the two operand streams,
+// the barriers and the stores cost alone), 2 = no LDS-DMA (what does the multiplication cost alone), 4 = MFMAs on constant fragments (no
+// LDS fragment reads).  tools/gemm_stream_bench.py over -DGS_WHATIF=... builds; profiles/r06_gemm_stream_whatif.txt
+#ifndef GS_WHATIF
+#define GS_WHATIF 0
+#endif
 #ifndef GS_ROT_SL
 #define GS_ROT_SL 2
 #endif
@@ -912,7 +918,7 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_
     auto issue_next = [&]() {
         int kc = ich + irot;
         if (kc >= nk) kc -= nk;
-        gs_issue_chunk(iA, a.lda, iB, a.ldb, (int64_t)kc * kstep, smem + islot * C::STAGE, wave, lane);
+        if (!(GS_WHATIF & 2)) gs_issue_chunk(iA, a.lda, iB, a.ldb, (int64_t)kc * kstep, smem + islot * C::STAGE, wave, lane);
         islot = (islot + 1) & (C::RING - 1);
         if (++ich == nk) {
             ich = 0;
@@ -953,16 +959,22 @@ __global__ __launch_bounds__(64 * GP_WAVES, 1) void gemm_stream_kernel(cad_gemm_
             if (it + C::RING - 1 < total) issue_next();
             const char* st = smem + slot * C::STAGE;
             slot = (slot + 1) & (C::RING - 1);
+            if (GS_WHATIF & 1) continue;
             u32x4 bfr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (GS_WHATIF & 4) {
+                    bfr[j] = u32x4{(uint32_t)(lane + j), (uint32_t)it, 0x3f803f80u, (uint32_t)slot};
+                    continue;
+                }
                 const u32x2 lo = cad_lds_read_tr16(st + b_off0 + ((j ^ bs0) * 32));
                 const u32x2 hi = cad_lds_read_tr16(st + b_off1 + ((j ^ bs1) * 32));
                 bfr[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const u32x4 af = *(const u32x4*)(st + a_off + i * 16 * C::AROW);
+                const u32x4 af = (GS_WHATIF & 4) ? u32x4{(uint32_t)(lane ^ i), 0x3f803f80u, (uint32_t)it, 0u}
+                                                  : *(const u32x4*)(st + a_off + i * 16 * C::AROW);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = cad_mfma_16x16x32_bf16(af, bfr[j], acc[i][j]);
             }

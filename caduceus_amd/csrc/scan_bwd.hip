@@ -1304,17 +1304,10 @@ extern "C" int cad_scan_bwd(const cad_scan_bwd_args* a, void* stream) { return c
 
 // diagnostic (tools/gpu_w4.sh): how many workgroups of the production instantiation the runtime places on one CU, and its LDS bytes
 extern "C" int cad_debug_scan_bwd_occupancy(int* out) {
-#ifndef CAD_EMU
     const size_t shmem = (size_t)(4 * SC_TILE(SC_S) + 2 * PK_BUF) * sizeof(float) + PRE_BYTES;
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_bwd_kernel<bf16_t, true, false, SC_BWD_UNROLL_NP>, 64 * SC_W, shmem) != hipSuccess)
-        return CAD_ERR_LAUNCH;
-    out[0] = nb, out[1] = (int)shmem, out[2] = SC_W;
-    return CAD_OK;
-#else
-    (void)out;
-    return CAD_ERR_UNSUPPORTED;
-#endif
+    out[0] = CAD_OCCUPANCY((scan_bwd_kernel<bf16_t, true, false, SC_BWD_UNROLL_NP>), 64 * SC_W, shmem);
+    out[1] = (int)shmem, out[2] = SC_W;
+    return out[0] > 0 ? CAD_OK : CAD_ERR_UNSUPPORTED;
 }
 
 extern "C" int64_t cad_scan_gate_fix_entries(int E, int64_t SB, int64_t L) {

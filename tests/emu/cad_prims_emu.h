@@ -94,19 +94,18 @@ __device__ __forceinline__ f32x4 cad_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 
     const int col = lane & 15, rg = lane >> 4;
     float bk[32];      // B[k][col]
     float ak[4][32];   // A[4 rg + r][k]
-    for (int g = 0; g < 4; ++g) {
-        for (int h = 0; h < 2; ++h) {
-            const uint64_t mine_b = (uint64_t)b[2 * h] | ((uint64_t)b[2 * h + 1] << 32);
-            const uint64_t vb = emu_exchange(mine_b, g * 16 + col);
-            for (int t = 0; t < 4; ++t)
-                bk[8 * g + 4 * h + t] = cad_bits2f((uint32_t)((vb >> (16 * t)) & 0xffffu) << 16);
-            const uint64_t mine_a = (uint64_t)a[2 * h] | ((uint64_t)a[2 * h + 1] << 32);
-            for (int r = 0; r < 4; ++r) {
-                const uint64_t va = emu_exchange(mine_a, g * 16 + 4 * rg + r);
-                for (int t = 0; t < 4; ++t)
-                    ak[r][8 * g + 4 * h + t] = cad_bits2f((uint32_t)((va >> (16 * t)) & 0xffffu) << 16);
-            }
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t* pb = emu_publish((uint64_t)b[2 * h] | ((uint64_t)b[2 * h + 1] << 32));
+        for (int g = 0; g < 4; ++g) {
+            const uint64_t vb = pb[g * 16 + col];
+            for (int t = 0; t < 4; ++t) bk[8 * g + 4 * h + t] = cad_bits2f((uint32_t)((vb >> (16 * t)) & 0xffffu) << 16);
         }
+        const uint64_t* pa = emu_publish((uint64_t)a[2 * h] | ((uint64_t)a[2 * h + 1] << 32));
+        for (int g = 0; g < 4; ++g)
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t va = pa[g * 16 + 4 * rg + r];
+                for (int t = 0; t < 4; ++t) ak[r][8 * g + 4 * h + t] = cad_bits2f((uint32_t)((va >> (16 * t)) & 0xffffu) << 16);
+            }
     }
     f32x4 d = c;
     for (int r = 0; r < 4; ++r) {
@@ -120,10 +119,14 @@ __device__ __forceinline__ f32x4 cad_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 
 __device__ __forceinline__ f32x4 cad_mfma_16x16x4_f32(float a, float b, f32x4 c) {
     const int lane = emu::lane_id();
     const int col = lane & 15, rg = lane >> 4;
+    uint32_t ab[2];
+    std::memcpy(&ab[0], &a, 4);
+    std::memcpy(&ab[1], &b, 4);
+    const uint64_t* p = emu_publish((uint64_t)ab[0] | ((uint64_t)ab[1] << 32));  // every lane's (a, b) in one rendezvous
     f32x4 d = c;
     for (int k = 0; k < 4; ++k) {
-        const float bk = emu_exchange(b, k * 16 + col);
-        for (int r = 0; r < 4; ++r) d[r] += emu_exchange(a, k * 16 + 4 * rg + r) * bk;
+        const float bk = cad_bits2f((uint32_t)(p[k * 16 + col] >> 32));
+        for (int r = 0; r < 4; ++r) d[r] += cad_bits2f((uint32_t)p[k * 16 + 4 * rg + r]) * bk;
     }
     return d;
 }
@@ -134,8 +137,9 @@ __device__ __forceinline__ u32x2 cad_lds_read_tr16(const void* p) {
     const int lane = emu::lane_id();
     const int base = lane & ~15, l = lane & 15;
     uint32_t e[4];
+    const uint64_t* p4 = emu_publish(mine);
     for (int r = 0; r < 4; ++r) {
-        const uint64_t v = emu_exchange(mine, base + 4 * r + (l >> 2));
+        const uint64_t v = p4[base + 4 * r + (l >> 2)];
         e[r] = (uint32_t)((v >> (16 * (l & 3))) & 0xffffu);
     }
     u32x2 out;
@@ -194,6 +198,7 @@ __device__ __forceinline__ uint64_t cad_wall_clock() {
 #define CAD_WALL_CLOCK_TICKS_PER_US 100ull  /* the wall clock of the device side runs at 100 MHz */
 __device__ __forceinline__ uint64_t cad_wall_clock_hz() { return 100000000ull; }
 #define CAD_BIG_LDS(kern, bytes) (void)0
+#define CAD_OCCUPANCY(kern, threads, bytes) 0  /* no CUs on the host */
 
 static inline float cad_e4m3_to_f32(uint8_t v) {
     const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
@@ -237,14 +242,17 @@ __device__ __forceinline__ f32x4 cad_mfma_16x16x32_fp8(u32x2 a, u32x2 b, f32x4 c
     const int col = lane & 15, rg = lane >> 4;
     float bk[32], ak[4][32];
     const uint64_t mine_a = (uint64_t)a[0] | ((uint64_t)a[1] << 32), mine_b = (uint64_t)b[0] | ((uint64_t)b[1] << 32);
+    const uint64_t* pb = emu_publish(mine_b);
     for (int g = 0; g < 4; ++g) {
-        const uint64_t vb = emu_exchange(mine_b, g * 16 + col);
+        const uint64_t vb = pb[g * 16 + col];
         for (int t = 0; t < 8; ++t) bk[8 * g + t] = cad_e4m3_to_f32((uint8_t)(vb >> (8 * t)));
+    }
+    const uint64_t* pa = emu_publish(mine_a);
+    for (int g = 0; g < 4; ++g)
         for (int r = 0; r < 4; ++r) {
-            const uint64_t va = emu_exchange(mine_a, g * 16 + 4 * rg + r);
+            const uint64_t va = pa[g * 16 + 4 * rg + r];
             for (int t = 0; t < 8; ++t) ak[r][8 * g + t] = cad_e4m3_to_f32((uint8_t)(va >> (8 * t)));
         }
-    }
     f32x4 d = c;
     for (int r = 0; r < 4; ++r) {
         float s = c[r];

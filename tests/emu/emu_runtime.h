@@ -68,6 +68,17 @@ inline T emu_exchange(T v, int src_lane) {
     std::memcpy(&out, &r, sizeof(T));
     return out;
 }
+// One rendezvous, many reads: every lane publishes 8 bytes and may then read ANY lane's slot until its own next publish / exchange (the
+// slots are double buffered by parity and no lane can be two rendezvous ahead of another lane of its wave).  The matrix-core primitives
+// gather their 16 x 4 / 16 x 32 operand panels with 1 / 4 of these instead of 20 / 40 single-slot exchanges.
+inline const uint64_t* emu_publish(uint64_t raw) {
+    int& par = emu::lane_parity();
+    uint64_t* buf = emu::wave_buf() + 64 * par;
+    par ^= 1;
+    buf[emu::lane_id()] = raw;
+    emu::wave_sync();
+    return buf;
+}
 template <class T>
 inline T __shfl(T v, int src, int width = 64) {
     int lane = emu::lane_id();
