@@ -7,72 +7,86 @@
 //
 // A workgroup (4 waves as 2 x 2) owns a 128 x 128 tile of D, a wave 64 x 64 of it (4 x 4 MFMA tiles = 64 accumulator registers) -- or,
 // where that would leave CUs idle or multiply padding (few tiles, thin M / N: x_proj's 48 rows, BASELINE configs[0]'s 2048 tokens), a
-// 64 x 64 tile with 2 x 2 MFMA tiles per wave; k is walked in chunks of 16 through ONE LDS stage per operand, the next chunk's global
-// loads in flight (registers) while the current one is multiplied.  LDS layouts follow the operand's contiguous direction so that both
-// the global loads (consecutive lanes = consecutive addresses) and the fragment reads (lane (g, jl): row jl, k = g) are bank-conflict-
-// free: [row][k] with 17-float rows for a k-contiguous operand, [k][row] with (tile + 16)-float rows for a row-contiguous one.
+// 64 x 64 tile with 2 x 2 MFMA tiles per wave; k is walked in chunks of 32 through ONE LDS stage per operand, the next chunk's global
+// loads in flight (registers) while the current one is multiplied.  A thread's elements of a chunk lie at ONE constant stride from a
+// per-thread base pointer (consecutive lanes walk the operand's contiguous direction), so the address arithmetic is a pointer and an
+// increment, not an index product per element.  LDS layouts follow the contiguous direction: [row][k] with 36-float rows for a
+// k-contiguous operand -- an MFMA k slot g takes the 8 consecutive k = 8 g .. 8 g + 7 of the chunk over its eight k-steps, so a fragment
+// is two ds_read_b128 -- and [k][row] with (tile + 16)-float rows for a row-contiguous one (eight ds_read_b32).
 #include "cad_common.h"
 
 namespace {
 
-constexpr int GF_KC = 16, GF_T = 256;
-constexpr int GF_KSTR = GF_KC + 1;    // floats per row of the [row][k] layout
+constexpr int GF_KC = 32, GF_T = 256;
+constexpr int GF_KSTR = GF_KC + 4;    // floats per row of the [row][k] layout (16-byte aligned rows)
 // WT = MFMA tiles per wave and dimension (4: 128 x 128 workgroup tile, 2: 64 x 64); BT = rows (= columns) of the workgroup tile
 template <int WT>
 struct GfCfg {
     static constexpr int BT = 32 * WT;
     static constexpr int RSTR = BT + 16;              // floats per k of the [k][row] layout (16 mod 32 banks: the two k of a half-wave do not collide)
     static constexpr int PER = BT * GF_KC / GF_T;     // elements per thread, operand and chunk
+    static constexpr int KPT = GF_T / BT;             // row-contiguous staging: k rows covered by the 256 threads at once
 };
 
-// element i (of BT x GF_KC) of an operand tile -> (row r inside the tile, k inside the chunk); consecutive lanes walk the contiguous direction
+// Staging map of one operand tile (BT rows x GF_KC k): thread t owns PER elements (row r0 + j dr, k k0 + j dk).
+//   k-contiguous operand:   k = t & 31 (fixed), rows (t >> 5) + 8 j       -- a wave reads two 128-byte row pieces per instruction
+//   row-contiguous operand: row = t % BT (fixed), k = t / BT + KPT j      -- a wave reads 256 contiguous bytes per instruction
 template <bool KFAST, int WT>
-__device__ __forceinline__ void gf_elem(int i, int& r, int& k) {
+struct GfMap {
+    static constexpr int dr = KFAST ? GF_T / GF_KC : 0, dk = KFAST ? 0 : GfCfg<WT>::KPT;
+    static __device__ __forceinline__ int r0(int t) { return KFAST ? (t >> 5) : (t & (GfCfg<WT>::BT - 1)); }
+    static __device__ __forceinline__ int k0(int t) { return KFAST ? (t & (GF_KC - 1)) : (t / GfCfg<WT>::BT); }
+    static __device__ __forceinline__ int lds(int r, int k) { return KFAST ? r * GF_KSTR + k : k * GfCfg<WT>::RSTR + r; }
+};
+
+// the eight k values of MFMA slot g (k = 8 g + s, s = k-step) of tile row `row`
+template <bool KFAST, int WT>
+__device__ __forceinline__ void gf_frag(const float* tile, int row, int g, float* f) {
     if constexpr (KFAST) {
-        k = i & (GF_KC - 1), r = i >> 4;
+        const f32x4 lo = *(const f32x4*)(tile + row * GF_KSTR + 8 * g), hi = *(const f32x4*)(tile + row * GF_KSTR + 8 * g + 4);
+        f[0] = lo[0], f[1] = lo[1], f[2] = lo[2], f[3] = lo[3], f[4] = hi[0], f[5] = hi[1], f[6] = hi[2], f[7] = hi[3];
     } else {
-        r = i & (GfCfg<WT>::BT - 1), k = i / GfCfg<WT>::BT;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) f[s] = tile[(8 * g + s) * GfCfg<WT>::RSTR + row];
     }
-}
-template <bool KFAST, int WT>
-__device__ __forceinline__ int gf_lds(int r, int k) {
-    return KFAST ? r * GF_KSTR + k : k * GfCfg<WT>::RSTR + r;
 }
 
 // KA / KB: the operand's k direction is the contiguous one (A row-major; B "column-major" = the transposed view of a row-major matrix)
 template <bool KA, bool KB, int WT>
-__global__ __launch_bounds__(GF_T) void gemm_f32_kernel(cad_gemm_f32_args a) {
+__global__ __launch_bounds__(GF_T, 2) void gemm_f32_kernel(cad_gemm_f32_args a) {
     typedef GfCfg<WT> C;
-    constexpr int GF_BM = C::BT, GF_BN = C::BT, GF_PER = C::PER, WS = 16 * WT;  // WS: rows (= columns) of a wave's share
-    __shared__ float As[KA ? C::BT * GF_KSTR : GF_KC * C::RSTR];
-    __shared__ float Bs[KB ? C::BT * GF_KSTR : GF_KC * C::RSTR];
+    typedef GfMap<KA, WT> MA;
+    typedef GfMap<KB, WT> MB;
+    constexpr int PER = C::PER, WS = 16 * WT;  // WS: rows (= columns) of a wave's share
+    __shared__ __attribute__((aligned(16))) float As[KA ? C::BT * GF_KSTR : GF_KC * C::RSTR];
+    __shared__ __attribute__((aligned(16))) float Bs[KB ? C::BT * GF_KSTR : GF_KC * C::RSTR];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int g = lane >> 4, jl = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * GF_BM, n0 = (int64_t)blockIdx.x * GF_BN;
-    const float* A = a.A + (int64_t)blockIdx.z * a.a_bs;
-    const float* B = a.B + (int64_t)blockIdx.z * a.b_bs;
-    float ra[GF_PER], rb[GF_PER];
+    const int64_t m0 = (int64_t)blockIdx.y * C::BT, n0 = (int64_t)blockIdx.x * C::BT;
+    // per-thread staging bases and increments (elements)
+    const int ar0 = MA::r0(t), ak0 = MA::k0(t), br0 = MB::r0(t), bk0 = MB::k0(t);
+    const float* pa = a.A + (int64_t)blockIdx.z * a.a_bs + (m0 + ar0) * a.a_rs + ak0 * a.a_cs;
+    const float* pb = a.B + (int64_t)blockIdx.z * a.b_bs + (n0 + br0) * a.b_cs + bk0 * a.b_rs;
+    const int64_t astep = MA::dr * a.a_rs + MA::dk * a.a_cs, bstep = MB::dr * a.b_cs + MB::dk * a.b_rs;
+    const int64_t arows = a.M - m0 - ar0, brows = a.N - n0 - br0;  // element j is inside the matrix while j dr < rows ...
+    float ra[PER], rb[PER];
     auto fetch = [&](int64_t k0) {
+        const float* qa = pa + k0 * a.a_cs;
+        const float* qb = pb + k0 * a.b_rs;
+        const int64_t aks = a.K - k0 - ak0, bks = a.K - k0 - bk0;  // ... and j dk < ks
 #pragma unroll
-        for (int j = 0; j < GF_PER; ++j) {
-            int r, k;
-            gf_elem<KA, WT>(t + GF_T * j, r, k);
-            const int64_t m = m0 + r, kk = k0 + k;
-            ra[j] = (m < a.M && kk < a.K) ? A[m * a.a_rs + kk * a.a_cs] : 0.f;
-            gf_elem<KB, WT>(t + GF_T * j, r, k);
-            const int64_t n = n0 + r, kb = k0 + k;
-            rb[j] = (n < a.N && kb < a.K) ? B[kb * a.b_rs + n * a.b_cs] : 0.f;
+        for (int j = 0; j < PER; ++j) {  // (running pointers: one 64-bit add per element instead of PER live addresses)
+            ra[j] = (j * MA::dr < arows && j * MA::dk < aks) ? *qa : 0.f;
+            rb[j] = (j * MB::dr < brows && j * MB::dk < bks) ? *qb : 0.f;
+            qa += astep, qb += bstep;
         }
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int j = 0; j < GF_PER; ++j) {
-            int r, k;
-            gf_elem<KA, WT>(t + GF_T * j, r, k);
-            As[gf_lds<KA, WT>(r, k)] = ra[j];
-            gf_elem<KB, WT>(t + GF_T * j, r, k);
-            Bs[gf_lds<KB, WT>(r, k)] = rb[j];
+        for (int j = 0; j < PER; ++j) {
+            As[MA::lds(ar0 + j * MA::dr, ak0 + j * MA::dk)] = ra[j];
+            Bs[MB::lds(br0 + j * MB::dr, bk0 + j * MB::dk)] = rb[j];
         }
     };
     f32x4 acc[WT][WT];
@@ -86,17 +100,18 @@ __global__ __launch_bounds__(GF_T) void gemm_f32_kernel(cad_gemm_f32_args a) {
     for (int64_t k0 = 0; k0 < a.K; k0 += GF_KC) {
         const bool more = k0 + GF_KC < a.K;
         if (more) fetch(k0 + GF_KC);
+        // the B fragments of the wave's WT column tiles stay in registers for the chunk, the A fragments come one row tile at a time
+        float bf[WT][8];
 #pragma unroll
-        for (int ks = 0; ks < GF_KC; ks += 4) {
-            float af[WT], bf[WT];
+        for (int j = 0; j < WT; ++j) gf_frag<KB, WT>(Bs, wn * WS + 16 * j + jl, g, bf[j]);
 #pragma unroll
-            for (int i = 0; i < WT; ++i) af[i] = As[gf_lds<KA, WT>(wm * WS + 16 * i + jl, ks + g)];
+        for (int i = 0; i < WT; ++i) {
+            float af[8];
+            gf_frag<KA, WT>(As, wm * WS + 16 * i + jl, g, af);
 #pragma unroll
-            for (int j = 0; j < WT; ++j) bf[j] = Bs[gf_lds<KB, WT>(wn * WS + 16 * j + jl, ks + g)];
+            for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int i = 0; i < WT; ++i)
-#pragma unroll
-                for (int j = 0; j < WT; ++j) acc[i][j] = cad_mfma_16x16x4_f32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < WT; ++j) acc[i][j] = cad_mfma_16x16x4_f32(af[s], bf[j][s], acc[i][j]);
         }
         __syncthreads();  // every wave has read the stage
         if (more) {

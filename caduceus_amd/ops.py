@@ -670,8 +670,8 @@ def mm_f32(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
     if a.dim() != 2 or b.dim() != 2:
         raise ValueError("mm_f32: 2-D operands")
     M, K = a.shape
-    N = b.shape[1] if b.dim() == 2 else 0
-    n = _f32_kslices(M, N, K) if b.shape[0] == K else 1
+    N = b.shape[1]
+    n = _f32_kslices(M, N, K) if b.shape[0] == K else 1  # (a shape mismatch is reported by _gemm_f32)
     if n > 1:
         Kc = K // n
         part = _gemm_f32(a.unflatten(1, (n, Kc)).permute(1, 0, 2), b.unflatten(0, (n, Kc)), None, None)  # (n, M, N)
