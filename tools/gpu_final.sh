@@ -42,3 +42,9 @@ timeout 900 bash tools/prof_step_c4.sh 2>&1 | grep -v "^W2026" | cut -c1-200 | h
 CADUCEUS_DP_FORCE_COLLECTIVE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --cpu-sample 0 --no-floor > gpurun_out/bench_torchrun_1rank_rccl.log 2>/dev/null; tail -1 gpurun_out/bench_torchrun_1rank_rccl.log | cut -c1-200
 timeout 300 python bench.py --global-batch 8 --steps 2 --warmup 1 --cpu-sample 0 --no-floor > gpurun_out/bench_global_batch8_1gpu.log 2>/dev/null; tail -1 gpurun_out/bench_global_batch8_1gpu.log | cut -c1-200
 fi
+if [ "$1" = all ]; then
+# the fp32 path: parity, cad_gemm_f32 against hipBLASLt, step traces without a library GEMM
+bash tools/gpu_f32.sh > gpurun_out/gpu_f32.log 2>&1; grep -n "passed\|library GEMM" gpurun_out/gpu_f32.log | cut -c1-160
+# the instruction prices bench.py's roofline.valu uses (VALU_PRICE_NS), re-measured on this box
+(cd /tmp && timeout 300 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench "$OLDPWD/tools/ubench/ubench.hip" 2>/dev/null && timeout 300 /tmp/ubench) > gpurun_out/ubench_gfx950.log 2>&1; grep -c "waves/SIMD=2" gpurun_out/ubench_gfx950.log
+fi
