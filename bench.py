@@ -182,7 +182,8 @@ def cpu_baseline_worker(scan_L=131072, reps_model=15, reps_scan=3):
 
 # Issue price of one wave instruction on one SIMD with two resident waves, ns, by instruction class -- this chip's micro-benchmark
 # (tools/ubench/ubench.hip, profiles/r01_ubench_gfx950.log: SIMD ticks per instruction at waves/SIMD = 2: v_mul / v_mov 2.2, v_fma 2.8,
-# v_pk_* and v_cvt_pk 3.6, VOP2 + DPP 3.5, v_exp / v_log / v_rcp 6.2, at the ~1.85 ticks per ns of that run).  "plain" = non-packed
+# v_pk_* and v_cvt_pk 3.6, VOP2 + DPP 3.5, v_exp / v_log / v_rcp 6.2, at the ~1.85 ticks per ns of that run; re-measured in round 6 on the
+# final build's box, profiles/r06_ubench_gfx950.log: the same ns per instruction to two digits).  "plain" = non-packed
 # VALU incl. moves, selects and v_readlane (between v_mul and v_fma).
 VALU_PRICE_NS = {"valu": 1.15, "valu_mov": 1.0, "valu_sel": 1.0, "valu_lane": 1.0, "valu_pk": 1.95, "valu_dpp": 1.9, "valu_cvt": 1.98,
                  "trans": 3.4}
